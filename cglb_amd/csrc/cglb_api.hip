@@ -1,0 +1,693 @@
+// C ABI of libcglb_hip.so: context, common terms (rocSOLVER/rocBLAS for the true dense contractions),
+// preconditioner, PCG loop, objective assembly and analytic gradient.  See include/cglb_hip.h.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "devmath.h"
+#include "dispatch.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// scalar slots in ctx->scal
+enum { S_RZ = 0, S_PAP = 1, S_NRZ = 2, S_TRACE = 3, S_SUMLOG = 4, S_TRBINV = 5, S_TMP = 6, S_SC = 8, S_TMP2 = 16 };
+
+// ---- typed rocBLAS / rocSOLVER wrappers ---------------------------------------------------------------
+inline rocblas_status xpotrf(rocblas_handle h, rocblas_fill u, int n, double* A, int lda, rocblas_int* info) { return rocsolver_dpotrf(h, u, n, A, lda, info); }
+inline rocblas_status xpotrf(rocblas_handle h, rocblas_fill u, int n, float* A, int lda, rocblas_int* info) { return rocsolver_spotrf(h, u, n, A, lda, info); }
+inline rocblas_status xtrtri(rocblas_handle h, rocblas_fill u, rocblas_diagonal d, int n, double* A, int lda, rocblas_int* info) { return rocsolver_dtrtri(h, u, d, n, A, lda, info); }
+inline rocblas_status xtrtri(rocblas_handle h, rocblas_fill u, rocblas_diagonal d, int n, float* A, int lda, rocblas_int* info) { return rocsolver_strtri(h, u, d, n, A, lda, info); }
+inline rocblas_status xtrsm(rocblas_handle h, rocblas_side s, rocblas_fill u, rocblas_operation t, rocblas_diagonal d, int m, int n, const double* al, const double* A, int lda, double* B, int ldb) { return rocblas_dtrsm(h, s, u, t, d, m, n, al, A, lda, B, ldb); }
+inline rocblas_status xtrsm(rocblas_handle h, rocblas_side s, rocblas_fill u, rocblas_operation t, rocblas_diagonal d, int m, int n, const float* al, const float* A, int lda, float* B, int ldb) { return rocblas_strsm(h, s, u, t, d, m, n, al, A, lda, B, ldb); }
+inline rocblas_status xsyrk(rocblas_handle h, rocblas_fill u, rocblas_operation t, int n, int k, const double* al, const double* A, int lda, const double* be, double* C, int ldc) { return rocblas_dsyrk(h, u, t, n, k, al, A, lda, be, C, ldc); }
+inline rocblas_status xsyrk(rocblas_handle h, rocblas_fill u, rocblas_operation t, int n, int k, const float* al, const float* A, int lda, const float* be, float* C, int ldc) { return rocblas_ssyrk(h, u, t, n, k, al, A, lda, be, C, ldc); }
+inline rocblas_status xgemm(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double* al, const double* A, int lda, const double* B, int ldb, const double* be, double* C, int ldc) { return rocblas_dgemm(h, ta, tb, m, n, k, al, A, lda, B, ldb, be, C, ldc); }
+inline rocblas_status xgemm(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const float* al, const float* A, int lda, const float* B, int ldb, const float* be, float* C, int ldc) { return rocblas_sgemm(h, ta, tb, m, n, k, al, A, lda, B, ldb, be, C, ldc); }
+inline rocblas_status xtrsv(rocblas_handle h, rocblas_fill u, rocblas_operation t, rocblas_diagonal d, int n, const double* A, int lda, double* x, int inc) { return rocblas_dtrsv(h, u, t, d, n, A, lda, x, inc); }
+inline rocblas_status xtrsv(rocblas_handle h, rocblas_fill u, rocblas_operation t, rocblas_diagonal d, int n, const float* A, int lda, float* x, int inc) { return rocblas_strsv(h, u, t, d, n, A, lda, x, inc); }
+
+// ---- small helper kernels -------------------------------------------------------------------------------
+// out = a * I + b * X + c * Y   (M x M, column-major; Y may be null)
+template <typename T>
+__global__ __launch_bounds__(256) void mat_combine_kernel(T* __restrict__ out, int M, T a, T b, const T* __restrict__ X, T cc, const T* __restrict__ Y) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * M) return;
+    const int i = (int)(idx % M), j = (int)(idx / M);
+    T v = b * X[idx];
+    if (Y) v = tfma<T>(cc, Y[idx], v);
+    if (i == j) v += a;
+    out[idx] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trace_kernel(const T* __restrict__ Mc, int M, double* __restrict__ slot) {
+    __shared__ double smem[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) s += (double)Mc[(int64_t)i * M + i];
+    s = block_sum(s, smem);
+    if (threadIdx.x == 0) slot[0] = s;
+}
+
+// y = a * x (length n);  y2 = b * x optional
+template <typename T>
+__global__ __launch_bounds__(256) void scale2_kernel(const T* __restrict__ x, int64_t n, T a, T* __restrict__ y, T b, T* __restrict__ y2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T xv = x[i];
+        y[i] = a * xv;
+        if (y2) y2[i] = b * xv;
+    }
+}
+
+// out = a*x + b*y
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(T* __restrict__ out, T a, const T* __restrict__ x, T b, const T* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a * x[i] + b * y[i];
+}
+
+// scalar-only gradient terms (added once, by the shard that owns row 0)
+__global__ void grad_scalar_terms_kernel(double* __restrict__ out, int D, const double* __restrict__ sc, const double* __restrict__ trBinv,
+                                         double N, double M, double f, double s, double tau, double T) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[D] += sc[5] / f - N / (2.0 * tau * s);
+    out[D + 1] += sc[2] + 0.5 * sc[3] + (M - trBinv[0]) / (2.0 * s) - N / (2.0 * s) + N * f / (2.0 * tau * s * s) - T / (2.0 * tau * s);
+    out[D + 2] += sc[4];
+}
+
+// prediction epilogue: per new point n
+//   mean[n] = cg_mean[n] + sum_m tmp2[m][n] c[m] + mu ; var[n] = f + sum tmp2^2 - sum tmp1^2    (models.py:347-351)
+template <typename T>
+__global__ __launch_bounds__(256) void predict_finish_kernel(const T* __restrict__ tmp1, const T* __restrict__ tmp2, int64_t ld, int M,
+                                                             const T* __restrict__ cvec, int64_t n_new, T mu, T f, T* __restrict__ mean_io,
+                                                             T* __restrict__ var_out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_new) return;
+    T s1 = 0, s2 = 0, sm = 0;
+    for (int m = 0; m < M; ++m) {
+        const T a = tmp1[(int64_t)m * ld + n], b = tmp2[(int64_t)m * ld + n];
+        s1 = tfma<T>(a, a, s1);
+        s2 = tfma<T>(b, b, s2);
+        sm = tfma<T>(b, cvec[m], sm);
+    }
+    mean_io[n] = mean_io[n] + sm + mu;
+    var_out[n] = f + s2 - s1;
+}
+
+// Kus panel for prediction: out[m*ld + n] = var*kappa(z_m, xnew_n)
+template <typename T, int KIND, int DP>
+__global__ __launch_bounds__(256) void kus_kernel(const T* __restrict__ Zs, const T* __restrict__ XsNew, int64_t n_new, int64_t ld, int M, T var,
+                                                  T* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_new) return;
+    T x[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) x[d] = XsNew[n * DP + d];
+    const int m0 = blockIdx.y * 32, m1 = min(M, m0 + 32);
+    for (int m = m0; m < m1; ++m) {
+        T d2 = 0;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            const T df = Zs[(int64_t)m * DP + d] - x[d];
+            d2 = tfma<T>(df, df, d2);
+        }
+        out[(int64_t)m * ld + n] = var * kappa_from_d2<T, KIND>(d2);
+    }
+}
+
+inline int grid1d(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int dalloc(cglb_ctx* c, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    HIP_CHECK(c, hipMalloc(p, bytes));
+    return CGLB_OK;
+}
+
+int read_scalars(cglb_ctx* c, const double* dev, double* host, int n) {
+    HIP_CHECK(c, hipMemcpyAsync(host, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return CGLB_OK;
+}
+
+inline double tau_of(const cglb_ctx* c) { return 1.0 + c->var / c->noise - c->trace_AAt / (double)c->N; }
+
+// ---- common terms -------------------------------------------------------------------------------------------
+template <typename T>
+int setup_local_impl(cglb_ctx* c) {
+    if (!c->have_data || !c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_data and set_hypers must precede setup");
+    const int M = c->M;
+    // K_uu + jitter I -> L (models.py:200-202)
+    CGLB_TRY(launch_kuu(c));
+    BLAS_CHECK(c, xpotrf(c->blas, rocblas_fill_lower, M, (T*)c->Lc, M, c->info_dev));
+    rocblas_int info = 0;
+    HIP_CHECK(c, hipMemcpyAsync(&info, c->info_dev, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (info != 0) return cglb_fail(c, CGLB_ERR_NOT_PD, "cholesky(K_uu + jitter I) failed: leading minor " + std::to_string(info) + " not positive definite");
+    CGLB_TRY(launch_tri_clean(c, c->Lc, 1));
+    // K_uf shard -> A = L^-1 K_uf / sigma  (models.py:196-197, :206).  Column-major view: At (nloc x M) L^T = Kuf^T / sigma.
+    if (c->nloc > 0) {
+        CGLB_TRY(launch_kuf(c));
+        const T alpha = (T)(1.0 / std::sqrt(c->noise));
+        BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+                            (int)c->nloc, M, &alpha, (const T*)c->Lc, M, (T*)c->At, (int)c->lda));
+        // partial A A^T (models.py:207): C = At^T At
+        const T one = 1, zero = 0;
+        BLAS_CHECK(c, xsyrk(c->blas, rocblas_fill_lower, rocblas_operation_transpose, M, (int)c->nloc, &one, (const T*)c->At, (int)c->lda,
+                            &zero, (T*)c->AAt, M));
+        CGLB_TRY(launch_symmetrize_lower(c, c->AAt));
+    } else {
+        HIP_CHECK(c, hipMemsetAsync(c->AAt, 0, (size_t)M * M * c->esz, c->stream));
+    }
+    c->have_local = true;
+    c->have_terms = false;
+    return CGLB_OK;
+}
+
+template <typename T>
+int setup_finish_impl(cglb_ctx* c) {
+    if (!c->have_local) return cglb_fail(c, CGLB_ERR_STATE, "setup_local must precede setup_finish");
+    const int M = c->M;
+    const size_t mm = (size_t)M * M * c->esz;
+    // B = AA^T + I, LB = chol(B), tr(AA^T)  (models.py:208-211)
+    HIP_CHECK(c, hipMemcpyAsync(c->LBc, c->AAt, mm, hipMemcpyDeviceToDevice, c->stream));
+    CGLB_TRY(launch_add_identity_trace(c, c->LBc, c->scal + S_TRACE));
+    BLAS_CHECK(c, xpotrf(c->blas, rocblas_fill_lower, M, (T*)c->LBc, M, c->info_dev));
+    CGLB_TRY(launch_tri_clean(c, c->LBc, 1));
+    CGLB_TRY(launch_sum_log_diag(c, c->LBc, c->scal + S_SUMLOG));
+    // explicit triangular inverse of LB in both orientations (contiguous rows for the two products of
+    // LB^-T LB^-1 u, conjugate_gradient.py:106-107)
+    HIP_CHECK(c, hipMemcpyAsync(c->LBinv, c->LBc, mm, hipMemcpyDeviceToDevice, c->stream));
+    BLAS_CHECK(c, xtrtri(c->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, M, (T*)c->LBinv, M, c->info_dev + 1));
+    CGLB_TRY(launch_transpose(c, c->LBinv, c->LBinvT));
+    rocblas_int info[2] = {0, 0};
+    double sc[2];
+    HIP_CHECK(c, hipMemcpyAsync(info, c->info_dev, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+    CGLB_TRY(read_scalars(c, c->scal + S_TRACE, sc, 2));
+    if (info[0] != 0) return cglb_fail(c, CGLB_ERR_NOT_PD, "cholesky(A A^T + I) failed: leading minor " + std::to_string(info[0]));
+    if (info[1] != 0) return cglb_fail(c, CGLB_ERR_NOT_PD, "inverse of LB failed: zero pivot " + std::to_string(info[1]));
+    c->trace_AAt = sc[0];
+    c->sum_log_diag_LB = sc[1];
+    c->have_terms = true;
+    return CGLB_OK;
+}
+
+int precond_single(cglb_ctx* c, const void* r, void* z, double* rz_slot) {
+    CGLB_TRY(launch_gemv_u(c, r, c->w_u));
+    CGLB_TRY(launch_tri_apply(c, c->w_u, c->w_t));
+    CGLB_TRY(launch_precond_z(c, r, c->w_t, z, rz_slot));
+    return CGLB_OK;
+}
+
+int require_terms(cglb_ctx* c) {
+    if (!c->have_terms) return cglb_fail(c, CGLB_ERR_STATE, "common terms not computed (call cglb_setup)");
+    return CGLB_OK;
+}
+int require_single(cglb_ctx* c) {
+    if (c->r0 != 0 || c->r1 != c->N) return cglb_fail(c, CGLB_ERR_STATE, "fused call needs a single shard covering all rows");
+    return CGLB_OK;
+}
+
+// ---- PCG (conjugate_gradient.py:41-86) ----------------------------------------------------------------------
+int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter, int restart_iter, int* steps, double* half_rz) {
+    double* S = c->scal;
+    // :57-61  Av = A v ; r = b - Av ; z, rz = P(r) ; p = z
+    CGLB_TRY(launch_kff_matvec(c, v, c->w_Kv, nullptr));
+    CGLB_TRY(launch_residual(c, c->w_r, b, c->w_Kv));
+    CGLB_TRY(precond_single(c, c->w_r, c->w_z, S + S_RZ));
+    HIP_CHECK(c, hipMemcpyAsync(c->w_p, c->w_z, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
+    double rz = 0;
+    CGLB_TRY(read_scalars(c, S + S_RZ, &rz, 1));
+    int i = 0;
+    while (0.5 * rz > max_error && i < max_iter) {  // :65
+        CGLB_TRY(launch_kff_matvec(c, c->w_p, c->w_Ap, S + S_PAP));                                // :66 and (p*Ap).sum()
+        const int restart = (restart_iter > 0) && (i % restart_iter == restart_iter - 1);          // :70
+        CGLB_TRY(launch_update_v_r(c, v, c->w_r, c->w_p, c->w_Ap, S + S_RZ, S + S_PAP, !restart));  // :67-68, :72
+        if (restart) {
+            CGLB_TRY(launch_kff_matvec(c, v, c->w_Kv, nullptr));
+            CGLB_TRY(launch_residual(c, c->w_r, b, c->w_Kv));
+        }
+        CGLB_TRY(precond_single(c, c->w_r, c->w_z, S + S_NRZ));                                     // :73
+        CGLB_TRY(launch_update_p(c, c->w_p, c->w_z, S + S_NRZ, S + S_RZ, restart));                 // :75
+        HIP_CHECK(c, hipMemcpyAsync(S + S_RZ, S + S_NRZ, sizeof(double), hipMemcpyDeviceToDevice, c->stream));  // :76
+        CGLB_TRY(read_scalars(c, S + S_NRZ, &rz, 1));                                               // host test of :65 (and the sync of :80-81)
+        ++i;
+    }
+    if (steps) *steps = i;
+    if (half_rz) *half_rz = 0.5 * rz;  // :83
+    return CGLB_OK;
+}
+
+// ---- objective phases -----------------------------------------------------------------------------------------
+int obj_phase1(cglb_ctx* c, const void* v_full, void* u_partial) {
+    const char* y_loc = (const char*)c->y + (size_t)c->r0 * c->esz;
+    CGLB_TRY(launch_sub_scalar(c, c->w_e, y_loc, c->mean, c->nloc));       // models.py:253-254
+    CGLB_TRY(launch_kff_matvec(c, v_full, c->w_Kv, nullptr));              // :280
+    CGLB_TRY(launch_residual(c, c->w_r, c->w_e, c->w_Kv));                 // :281
+    CGLB_TRY(launch_gemv_u(c, c->w_r, u_partial));                         // first half of precon(r), :282
+    return CGLB_OK;
+}
+
+int obj_phase2(cglb_ctx* c, const void* v_full, const void* u, double* sc_partial, void* aw_partial) {
+    const char* v_loc = (const char*)v_full + (size_t)c->r0 * c->esz;
+    CGLB_TRY(launch_tri_apply(c, u, c->w_t));
+    CGLB_TRY(launch_precond_z(c, c->w_r, c->w_t, c->w_z, c->scal + S_TMP));  // w = P r
+    CGLB_TRY(launch_obj_scalars(c, v_loc, c->w_r, c->w_Kv, c->w_z, sc_partial));
+    CGLB_TRY(launch_gemv_u(c, c->w_z, aw_partial));                           // A w  (for c = Kuu^-1 Kuf w)
+    return CGLB_OK;
+}
+
+template <typename T>
+int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const void* aw, double* out) {
+    const int M = c->M, D = c->D;
+    const size_t glen = (size_t)CGLB_GRAD_LEN(D, M);
+    const double s = c->noise, f = c->var, sigma = std::sqrt(s), tau = tau_of(c);
+    const T one = 1, zero = 0;
+    HIP_CHECK(c, hipMemsetAsync(out, 0, glen * sizeof(double), c->stream));
+    if (!c->Guf) CGLB_TRY(dalloc(c, &c->Guf, (size_t)M * c->lda * c->esz));
+    // B^-1 = LB^-T LB^-1 and its trace
+    BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one, (const T*)c->LBinv, M, (const T*)c->LBinv, M,
+                        &zero, (T*)c->Mtmp, M));
+    hipLaunchKernelGGL((trace_kernel<T>), dim3(1), dim3(256), 0, c->stream, (const T*)c->Mtmp, M, c->scal + S_TRBINV);
+    // c = Kuu^-1 Kuf w = sigma L^-T (A w); mhalf = -c/2
+    HIP_CHECK(c, hipMemcpyAsync(c->w_t2, aw, (size_t)M * c->esz, hipMemcpyDeviceToDevice, c->stream));
+    BLAS_CHECK(c, xtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, (const T*)c->Lc, M, (T*)c->w_t2, 1));
+    hipLaunchKernelGGL((scale2_kernel<T>), dim3(grid1d(M)), dim3(256), 0, c->stream, (const T*)c->w_t2, (int64_t)M, (T)sigma, (T*)c->w_t2,
+                       (T)(-0.5 * sigma), (T*)c->w_t);
+    // Guf = (1/sigma) L^-T (I/tau - B^-1) A   (+ c w^T applied on the fly)
+    hipLaunchKernelGGL((mat_combine_kernel<T>), dim3(grid1d((int64_t)M * M)), dim3(256), 0, c->stream, (T*)c->Mtmp2, M, (T)(1.0 / tau), (T)-1,
+                       (const T*)c->Mtmp, (T)0, (const T*)nullptr);
+    const T inv_sigma = (T)(1.0 / sigma);
+    BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, M, &inv_sigma,
+                        (const T*)c->Lc, M, (T*)c->Mtmp2, M));
+    if (c->nloc > 0) {
+        BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, (int)c->nloc, M, M, &one, (const T*)c->At, (int)c->lda,
+                            (const T*)c->Mtmp2, M, &zero, (T*)c->Guf, (int)c->lda));
+        CGLB_TRY(launch_grad_kuf(c, c->w_t2, c->w_z, out));
+        // u = w + v/2 ; N^2 bilinear pass
+        const T* v_loc = (const T*)v_full + c->r0;
+        hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid1d(c->nloc)), dim3(256), 0, c->stream, (T*)c->w_Ap, (T)1, (const T*)c->w_z, (T)0.5, v_loc,
+                           c->nloc);
+        CGLB_TRY(launch_grad_kff(c, v_full, c->w_Ap, c->scal + S_TMP2));
+        hipLaunchKernelGGL((axpby_kernel<double>), dim3(1), dim3(64), 0, c->stream, out, 1.0, (const double*)out, 1.0,
+                           (const double*)(c->scal + S_TMP2), (int64_t)D);
+    }
+    if (c->r0 == 0) {
+        // Guu = L^-T [ (I - B^-1)/2 - (AA^T)/(2 tau) ] L^-1  - c c^T/2
+        hipLaunchKernelGGL((mat_combine_kernel<T>), dim3(grid1d((int64_t)M * M)), dim3(256), 0, c->stream, (T*)c->Mtmp, M, (T)0.5, (T)-0.5,
+                           (const T*)c->Mtmp, (T)(-0.5 / tau), (const T*)c->AAt);
+        BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, M, &one,
+                            (const T*)c->Lc, M, (T*)c->Mtmp, M));
+        BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, M, M, &one,
+                            (const T*)c->Lc, M, (T*)c->Mtmp, M));
+        CGLB_TRY(launch_grad_kuu(c, c->Mtmp, c->w_t2, c->w_t, out));
+        hipLaunchKernelGGL(grad_scalar_terms_kernel, dim3(1), dim3(64), 0, c->stream, out, D, sc, (const double*)(c->scal + S_TRBINV), (double)c->N,
+                           (double)M, f, s, tau, c->trace_AAt);
+    }
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
+double logdet_value(const cglb_ctx* c) {
+    const double N = (double)c->N;
+    return -c->sum_log_diag_LB - 0.5 * N * std::log(c->noise) - 0.5 * N * std::log(tau_of(c));  // models.py:236-243
+}
+
+int obj_finish(cglb_ctx* c, const double* sc_dev, double* out4) {
+    double sc[8];
+    CGLB_TRY(read_scalars(c, sc_dev, sc, 8));
+    const double N = (double)c->N;
+    const double lower = sc[0], upper = sc[0] + 0.5 * sc[1];           // models.py:283-284
+    const double logdet = logdet_value(c);
+    const double cst = -0.5 * N * std::log(2.0 * M_PI);                  // models.py:162-163
+    out4[0] = -upper + logdet + cst;                                     // models.py:286, :169
+    out4[1] = lower;
+    out4[2] = upper;
+    out4[3] = logdet;
+    return CGLB_OK;
+}
+
+}  // namespace
+
+// =================================================== C ABI ====================================================
+extern "C" {
+
+int cglb_version(void) { return 100; }
+
+const char* cglb_last_error(const cglb_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t row_end, int d, int m, int dtype, int kernel_kind, int device,
+                    void* stream) {
+    g_create_error.clear();
+    if (!out) { g_create_error = "out is NULL"; return CGLB_ERR_BAD_ARG; }
+    *out = nullptr;
+    if (n_total <= 0 || row_begin < 0 || row_end < row_begin || row_end > n_total || d <= 0 || d > CGLB_MAX_D || m <= 0 ||
+        (dtype != CGLB_F64 && dtype != CGLB_F32) || (kernel_kind != CGLB_RBF && kernel_kind != CGLB_MATERN32)) {
+        g_create_error = "bad argument to cglb_ctx_create";
+        return CGLB_ERR_BAD_ARG;
+    }
+    if (n_total > 2000000000LL || (int64_t)m > 65536) { g_create_error = "problem too large for 32-bit BLAS dimensions"; return CGLB_ERR_BAD_ARG; }
+    cglb_ctx* c = new (std::nothrow) cglb_ctx();
+    if (!c) { g_create_error = "out of host memory"; return CGLB_ERR_BAD_ARG; }
+    c->N = n_total; c->r0 = row_begin; c->r1 = row_end; c->nloc = row_end - row_begin;
+    c->lda = (c->nloc + 7) & ~(int64_t)7; if (c->lda == 0) c->lda = 8;
+    c->D = d; c->Dp = pad_dim(d); c->M = m; c->dtype = dtype; c->kind = kernel_kind; c->device = device;
+    c->esz = dtype == CGLB_F64 ? 8 : 4; c->stream = (hipStream_t)stream;
+    auto fail = [&](int rc) { g_create_error = c->err; cglb_ctx_destroy(c); return rc; };
+#define CR(expr) do { int _rc = (expr); if (_rc != CGLB_OK) return fail(_rc); } while (0)
+    { hipError_t e = hipSetDevice(device); if (e != hipSuccess) { c->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return fail(CGLB_ERR_HIP); } }
+    { rocblas_status s = rocblas_create_handle(&c->blas); if (s != rocblas_status_success) { c->err = "rocblas_create_handle failed"; c->blas = nullptr; return fail(CGLB_ERR_BLAS); } }
+    { rocblas_status s = rocblas_set_stream(c->blas, c->stream); if (s != rocblas_status_success) { c->err = "rocblas_set_stream failed"; return fail(CGLB_ERR_BLAS); } }
+    const size_t e = c->esz, N = (size_t)c->N, nl = (size_t)c->nloc, M = (size_t)m, Dp = (size_t)c->Dp;
+    CR(dalloc(c, &c->X, N * d * e)); CR(dalloc(c, &c->y, N * e)); CR(dalloc(c, &c->Z, M * d * e));
+    CR(dalloc(c, &c->Xs, N * Dp * e)); CR(dalloc(c, &c->xa, N * e)); CR(dalloc(c, &c->Zs, M * Dp * e)); CR(dalloc(c, &c->za, M * e));
+    CR(dalloc(c, &c->At, M * (size_t)c->lda * e));
+    CR(dalloc(c, &c->Lc, M * M * e)); CR(dalloc(c, &c->LBc, M * M * e)); CR(dalloc(c, &c->LBinv, M * M * e)); CR(dalloc(c, &c->LBinvT, M * M * e));
+    CR(dalloc(c, &c->AAt, M * M * e)); CR(dalloc(c, &c->Mtmp, M * M * e)); CR(dalloc(c, &c->Mtmp2, M * M * e));
+    CR(dalloc(c, (void**)&c->info_dev, 4 * sizeof(rocblas_int)));
+    CR(dalloc(c, &c->w_r, nl * e)); CR(dalloc(c, &c->w_z, nl * e)); CR(dalloc(c, &c->w_p, nl * e)); CR(dalloc(c, &c->w_Ap, nl * e));
+    CR(dalloc(c, &c->w_Kv, nl * e)); CR(dalloc(c, &c->w_e, nl * e)); CR(dalloc(c, &c->w_pfull, N * e));
+    CR(dalloc(c, &c->w_u, M * e)); CR(dalloc(c, &c->w_t, M * e)); CR(dalloc(c, &c->w_t2, M * e));
+    CR(dalloc(c, &c->tpart, ((M + 63) / 64) * nl * e));
+    CR(dalloc(c, (void**)&c->dotpart, DOTPART_CAP * sizeof(double)));
+    CR(dalloc(c, (void**)&c->scal, 64 * sizeof(double)));
+    CR(dalloc(c, (void**)&c->gradbuf, (size_t)CGLB_GRAD_LEN(d, m) * sizeof(double)));
+    { hipError_t e2 = hipMemsetAsync(c->scal, 0, 64 * sizeof(double), c->stream); if (e2 != hipSuccess) { c->err = "memset failed"; return fail(CGLB_ERR_HIP); } }
+#undef CR
+    *out = c;
+    return CGLB_OK;
+}
+
+int cglb_ctx_destroy(cglb_ctx* c) {
+    if (!c) return CGLB_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
+    void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
+                    c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
+                    c->dotpart, c->scal, c->gpart, c->gradbuf};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->blas) (void)rocblas_destroy_handle(c->blas);
+    delete c;
+    return CGLB_OK;
+}
+
+int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return CGLB_ERR_BAD_ARG;
+    if (!strcmp(name, "kff_variant")) c->kff_variant = (int)value;
+    else if (!strcmp(name, "kff_jsplit")) c->kff_jsplit = (int)value;
+    else if (!strcmp(name, "kff_rows")) c->kff_rows = (int)value;
+    else return cglb_fail(c, CGLB_ERR_BAD_ARG, std::string("unknown option ") + name);
+    return CGLB_OK;
+}
+
+int cglb_set_data(cglb_ctx* c, const void* X, const void* y) {
+    if (!c || !X || !y) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    const size_t nx = (size_t)c->N * c->D;
+    HIP_CHECK(c, hipMemcpyAsync(c->X, X, nx * c->esz, hipMemcpyDefault, c->stream));
+    HIP_CHECK(c, hipMemcpyAsync(c->y, y, (size_t)c->N * c->esz, hipMemcpyDefault, c->stream));
+    // column means (centre of the Gram form; any centre is exact in exact arithmetic)
+    std::vector<char> host(nx * c->esz);
+    HIP_CHECK(c, hipMemcpyAsync(host.data(), c->X, nx * c->esz, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    for (int d = 0; d < c->D; ++d) c->xmean[d] = 0.0;
+    for (int64_t i = 0; i < c->N; ++i)
+        for (int d = 0; d < c->D; ++d)
+            c->xmean[d] += c->dtype == CGLB_F64 ? ((const double*)host.data())[i * c->D + d] : (double)((const float*)host.data())[i * c->D + d];
+    for (int d = 0; d < c->D; ++d) c->xmean[d] /= (double)c->N;
+    c->have_data = true;
+    c->have_local = c->have_terms = false;
+    return CGLB_OK;
+}
+
+int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, double noise, double mean, const void* Z, double jitter) {
+    if (!c || !lengthscales || !Z) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    if (!c->have_data) return cglb_fail(c, CGLB_ERR_STATE, "set_data must precede set_hypers");
+    if (!(variance > 0) || !(noise > 0) || !(jitter >= 0) || !std::isfinite(mean)) return cglb_fail(c, CGLB_ERR_BAD_ARG, "variance/noise must be positive, jitter >= 0");
+    for (int d = 0; d < c->D; ++d)
+        if (!(lengthscales[d] > 0) || !std::isfinite(lengthscales[d])) return cglb_fail(c, CGLB_ERR_BAD_ARG, "lengthscales must be positive");
+    HIP_CHECK(c, hipSetDevice(c->device));
+    for (int d = 0; d < c->D; ++d) c->ls[d] = lengthscales[d];
+    c->var = variance; c->noise = noise; c->mean = mean; c->jitter = jitter;
+    HIP_CHECK(c, hipMemcpyAsync(c->Z, Z, (size_t)c->M * c->D * c->esz, hipMemcpyDefault, c->stream));
+    c->have_hypers = true;
+    CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
+    CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zs, c->za));
+    c->have_local = c->have_terms = false;
+    return CGLB_OK;
+}
+
+int cglb_shard_setup_local(cglb_ctx* c) {
+    if (!c) return CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_DISPATCH_T(c->dtype, return setup_local_impl<T>(c));
+}
+void* cglb_aat_buffer(cglb_ctx* c) { return c ? c->AAt : nullptr; }
+int cglb_shard_setup_finish(cglb_ctx* c) {
+    if (!c) return CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_DISPATCH_T(c->dtype, return setup_finish_impl<T>(c));
+}
+int cglb_setup(cglb_ctx* c) {
+    if (!c) return CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_single(c));
+    CGLB_TRY(cglb_shard_setup_local(c));
+    return cglb_shard_setup_finish(c);
+}
+
+int cglb_logdet(cglb_ctx* c, double* logdet) {
+    if (!c || !logdet) return CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    *logdet = logdet_value(c);
+    return CGLB_OK;
+}
+
+int cglb_matvec(cglb_ctx* c, const void* p_full, void* out_local) {
+    if (!c || !p_full || !out_local) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede matvec");
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_kff_matvec(c, p_full, out_local, nullptr);
+}
+
+int cglb_cross_matvec(cglb_ctx* c, const void* xnew, int64_t n_new, const void* v_full, void* out) {
+    if (!c || !xnew || !v_full || !out || n_new < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede cross_matvec");
+    if (n_new == 0) return CGLB_OK;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    void *xr = nullptr, *xs = nullptr, *xa = nullptr;
+    HIP_CHECK(c, hipMalloc(&xr, (size_t)n_new * c->D * c->esz));
+    HIP_CHECK(c, hipMalloc(&xs, (size_t)n_new * c->Dp * c->esz));
+    HIP_CHECK(c, hipMalloc(&xa, (size_t)n_new * c->esz));
+    int rc = CGLB_OK;
+    hipError_t e = hipMemcpyAsync(xr, xnew, (size_t)n_new * c->D * c->esz, hipMemcpyDefault, c->stream);
+    if (e != hipSuccess) rc = cglb_fail(c, CGLB_ERR_HIP, "copy of xnew failed");
+    if (rc == CGLB_OK) rc = launch_prep_scaled(c, xr, n_new, xs, xa);
+    if (rc == CGLB_OK) rc = launch_cross_matvec(c, xs, xa, n_new, v_full, out);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(xr); (void)hipFree(xs); (void)hipFree(xa);
+    return rc;
+}
+
+int cglb_precond_apply(cglb_ctx* c, const void* r, void* z, double* rz) {
+    if (!c || !r || !z) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_single(c));
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_TRY(precond_single(c, r, z, c->scal + S_TMP));
+    if (rz) CGLB_TRY(read_scalars(c, c->scal + S_TMP, rz, 1));
+    return CGLB_OK;
+}
+
+int cglb_shard_precond_u(cglb_ctx* c, const void* r_local, void* u_partial) {
+    if (!c || !r_local || !u_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_gemv_u(c, r_local, u_partial);
+}
+int cglb_shard_precond_z(cglb_ctx* c, const void* r_local, const void* u, void* z_local, void* rz_partial) {
+    if (!c || !r_local || !u || !z_local || !rz_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_TRY(launch_tri_apply(c, u, c->w_t));
+    return launch_precond_z(c, r_local, c->w_t, z_local, (double*)rz_partial);
+}
+
+int cglb_shard_dot(cglb_ctx* c, const void* a_local, const void* b_local, void* out) {
+    if (!c || !a_local || !b_local || !out) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_dot(c, a_local, b_local, c->nloc, (double*)out);
+}
+int cglb_shard_update_v_r(cglb_ctx* c, void* v_local, void* r_local, const void* p_local, const void* Ap_local, const void* rz, const void* pAp,
+                          int update_r) {
+    if (!c || !v_local || !r_local || !p_local || !Ap_local || !rz || !pAp) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_update_v_r(c, v_local, r_local, p_local, Ap_local, (const double*)rz, (const double*)pAp, update_r);
+}
+int cglb_shard_residual(cglb_ctx* c, void* r_local, const void* b_local, const void* Kv_local) {
+    if (!c || !r_local || !b_local || !Kv_local) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_residual(c, r_local, b_local, Kv_local);
+}
+int cglb_shard_update_p(cglb_ctx* c, void* p_local, const void* z_local, const void* new_rz, const void* rz, int restart) {
+    if (!c || !p_local || !z_local || !new_rz || !rz) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_update_p(c, p_local, z_local, (const double*)new_rz, (const double*)rz, restart);
+}
+
+int cglb_pcg_solve(cglb_ctx* c, const void* b, void* v_inout, double max_error, int max_cg_iter, int restart_cg_iter, int* steps, double* half_rz) {
+    if (!c || !b || !v_inout) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_single(c));
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return pcg_impl(c, b, v_inout, max_error, max_cg_iter, restart_cg_iter, steps, half_rz);
+}
+
+int cglb_shard_obj_phase1(cglb_ctx* c, const void* v_full, void* u_partial) {
+    if (!c || !v_full || !u_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return obj_phase1(c, v_full, u_partial);
+}
+int cglb_shard_obj_phase2(cglb_ctx* c, const void* v_full, const void* u, void* sc_partial, void* aw_partial) {
+    if (!c || !v_full || !u || !sc_partial || !aw_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return obj_phase2(c, v_full, u, (double*)sc_partial, aw_partial);
+}
+int cglb_shard_obj_phase3(cglb_ctx* c, const void* v_full, const void* sc, const void* aw, void* grad_partial) {
+    if (!c || !v_full || !sc || !aw || !grad_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_DISPATCH_T(c->dtype, return obj_phase3_impl<T>(c, v_full, (const double*)sc, aw, (double*)grad_partial));
+}
+int cglb_shard_obj_finish(cglb_ctx* c, const void* sc, double* out4) {
+    if (!c || !sc || !out4) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return obj_finish(c, (const double*)sc, out4);
+}
+
+int cglb_objective_and_grad(cglb_ctx* c, void* v_inout, int run_cg, double max_error, int max_cg_iter, int restart_cg_iter, double* out4,
+                            double* grad, int* steps, double* half_rz) {
+    if (!c || !v_inout || !out4) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_single(c));
+    CGLB_TRY(cglb_setup(c));                                                        // models.py:155
+    if (steps) *steps = 0;
+    if (half_rz) *half_rz = std::nan("");
+    if (run_cg) {                                                                   // models.py:262-278
+        CGLB_TRY(launch_sub_scalar(c, c->w_e, c->y, c->mean, c->nloc));
+        // w_e is reused by phase1, which recomputes it; pcg reads it as b
+        CGLB_TRY(pcg_impl(c, c->w_e, v_inout, max_error, max_cg_iter, restart_cg_iter, steps, half_rz));
+    }
+    double* sc = c->scal + S_SC;
+    CGLB_TRY(obj_phase1(c, v_inout, c->w_u));
+    CGLB_TRY(obj_phase2(c, v_inout, c->w_u, sc, c->w_u));  // aw overwrites u after u has been consumed (stream order)
+    if (grad) {
+        CGLB_DISPATCH_T(c->dtype, CGLB_TRY(obj_phase3_impl<T>(c, v_inout, sc, c->w_u, c->gradbuf)));
+        HIP_CHECK(c, hipMemcpyAsync(grad, c->gradbuf, (size_t)CGLB_GRAD_LEN(c->D, c->M) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    return obj_finish(c, sc, out4);
+}
+
+int cglb_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var) {
+    if (!c || !v_full || !xnew || !f_mean || !f_var || n_new < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_single(c));
+    CGLB_TRY(require_terms(c));
+    if (n_new == 0) return CGLB_OK;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    const int M = c->M;
+    const int64_t ld = (n_new + 7) & ~(int64_t)7;
+    void *xr = nullptr, *xs = nullptr, *xa = nullptr, *t1 = nullptr, *t2 = nullptr;
+    HIP_CHECK(c, hipMalloc(&xr, (size_t)n_new * c->D * c->esz));
+    HIP_CHECK(c, hipMalloc(&xs, (size_t)n_new * c->Dp * c->esz));
+    HIP_CHECK(c, hipMalloc(&xa, (size_t)n_new * c->esz));
+    HIP_CHECK(c, hipMalloc(&t1, (size_t)M * ld * c->esz));
+    HIP_CHECK(c, hipMalloc(&t2, (size_t)M * ld * c->esz));
+    auto body = [&]() -> int {
+        HIP_CHECK(c, hipMemcpyAsync(xr, xnew, (size_t)n_new * c->D * c->esz, hipMemcpyDefault, c->stream));
+        CGLB_TRY(launch_prep_scaled(c, xr, n_new, xs, xa));
+        CGLB_TRY(launch_cross_matvec(c, xs, xa, n_new, v_full, f_mean));       // cg_mean = ksf @ v   (models.py:334)
+        CGLB_TRY(launch_sub_scalar(c, c->w_e, c->y, c->mean, c->nloc));        // err                  (:318)
+        CGLB_TRY(launch_kff_matvec(c, v_full, c->w_Kv, nullptr));
+        CGLB_TRY(launch_residual(c, c->w_r, c->w_e, c->w_Kv));                 // res = err - cov @ v  (:335)
+        CGLB_TRY(launch_gemv_u(c, c->w_r, c->w_u));                            // a_res = A @ res      (:340)
+        CGLB_DISPATCH_T(c->dtype, {
+            const T one = 1;
+            const T inv_sigma = (T)(1.0 / std::sqrt(c->noise));
+            // c = LB^-1 a_res / sigma (:343)
+            BLAS_CHECK(c, xtrsv(c->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, M, (const T*)c->LBc, M, (T*)c->w_u, 1));
+            hipLaunchKernelGGL((scale2_kernel<T>), dim3(grid1d(M)), dim3(256), 0, c->stream, (const T*)c->w_u, (int64_t)M, inv_sigma, (T*)c->w_u, (T)0, (T*)nullptr);
+            // tmp1 = L^-1 Kus (:344), tmp2 = LB^-1 tmp1 (:345); panels stored [M][ld] row-major == (ld x M) column-major
+            dim3 grid((unsigned)((n_new + 255) / 256), (unsigned)((M + 31) / 32));
+            CGLB_DISPATCH_KIND(c->kind, CGLB_DISPATCH_DP(c->Dp, hipLaunchKernelGGL((kus_kernel<T, KIND, DP>), grid, dim3(256), 0, c->stream, (const T*)c->Zs,
+                                                                                    (const T*)xs, n_new, ld, M, (T)c->var, (T*)t1)));
+            BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, (int)n_new, M, &one,
+                                (const T*)c->Lc, M, (T*)t1, (int)ld));
+            HIP_CHECK(c, hipMemcpyAsync(t2, t1, (size_t)M * ld * c->esz, hipMemcpyDeviceToDevice, c->stream));
+            BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, (int)n_new, M, &one,
+                                (const T*)c->LBc, M, (T*)t2, (int)ld));
+            hipLaunchKernelGGL((predict_finish_kernel<T>), dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, c->stream, (const T*)t1, (const T*)t2, ld, M,
+                               (const T*)c->w_u, n_new, (T)c->mean, (T)c->var, (T*)f_mean, (T*)f_var);
+        });
+        CGLB_LAUNCH_CHECK(c);
+        return CGLB_OK;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(xr); (void)hipFree(xs); (void)hipFree(xa); (void)hipFree(t1); (void)hipFree(t2);
+    return rc;
+}
+
+int cglb_get_matrix(cglb_ctx* c, int which, void* dst) {
+    if (!c || !dst) return CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    const size_t e = c->esz;
+    if (which == 0) {  // A [M][nloc] (strip the lda padding)
+        HIP_CHECK(c, hipMemcpy2DAsync(dst, (size_t)c->nloc * e, c->At, (size_t)c->lda * e, (size_t)c->nloc * e, (size_t)c->M, hipMemcpyDefault, c->stream));
+    } else if (which == 1 || which == 2) {  // column-major lower -> row-major lower via transpose into Mtmp2
+        CGLB_TRY(launch_transpose(c, which == 1 ? c->Lc : c->LBc, c->Mtmp2));
+        HIP_CHECK(c, hipMemcpyAsync(dst, c->Mtmp2, (size_t)c->M * c->M * e, hipMemcpyDefault, c->stream));
+    } else {
+        return cglb_fail(c, CGLB_ERR_BAD_ARG, "unknown matrix id");
+    }
+    HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return CGLB_OK;
+}
+
+int cglb_time_kernel(cglb_ctx* c, int which, int reps, double* ms_avg) {
+    if (!c || !ms_avg || reps <= 0) return CGLB_ERR_BAD_ARG;
+    if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede timing");
+    if (which != 0) CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    // operands: y as a generic vector (values do not change the instruction stream)
+    hipEvent_t e0, e1;
+    HIP_CHECK(c, hipEventCreate(&e0));
+    HIP_CHECK(c, hipEventCreate(&e1));
+    int rc = CGLB_OK;
+    auto once = [&]() -> int {
+        if (which == 0) return launch_kff_matvec(c, c->y, c->w_Ap, nullptr);
+        if (which == 1) return precond_single(c, (const char*)c->y + (size_t)c->r0 * c->esz, c->w_z, c->scal + S_TMP);
+        if (which == 2) return launch_grad_kff(c, c->y, (const char*)c->y + (size_t)c->r0 * c->esz, c->scal + S_TMP2);
+        return cglb_fail(c, CGLB_ERR_BAD_ARG, "unknown kernel id");
+    };
+    rc = once();  // warm-up (also sizes the work buffers)
+    if (rc == CGLB_OK) {
+        (void)hipEventRecord(e0, c->stream);
+        for (int i = 0; i < reps && rc == CGLB_OK; ++i) rc = once();
+        (void)hipEventRecord(e1, c->stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *ms_avg = (double)ms / reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// Internal declarations shared by the translation units of libcglb_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/cglb_hip.h"
+
+#define CGLB_MAX_D 32
+#define CGLB_WAVE 64
+
+struct cglb_ctx {
+    // geometry
+    int64_t N = 0, r0 = 0, r1 = 0, nloc = 0, lda = 0;  // lda: leading dimension of At/Guf (nloc rounded up to 8)
+    int D = 0, Dp = 0, M = 0, dtype = CGLB_F64, kind = CGLB_RBF, device = 0;
+    size_t esz = 8;
+    hipStream_t stream = nullptr;
+    rocblas_handle blas = nullptr;
+    // state flags
+    bool have_data = false, have_hypers = false, have_local = false, have_terms = false;
+    // raw data (element type T)
+    void *X = nullptr, *y = nullptr, *Z = nullptr;
+    double xmean[CGLB_MAX_D] = {0};  // column means of X (centre for the Gram form)
+    // hypers (host)
+    double ls[CGLB_MAX_D] = {0};
+    double var = 1, noise = 1, mean = 0, jitter = 1e-6;
+    // scaled operands of the streaming kernels (T): xs = (x-c)/l*kscale padded to Dp, xa = per-row norm term
+    void *Xs = nullptr, *xa = nullptr, *Zs = nullptr, *za = nullptr;
+    // common terms (column-major M x M unless noted)
+    void* At = nullptr;      // A as [M][nloc] row-major == (nloc x M) column-major, ld = nloc
+    void* Lc = nullptr;      // chol(Kuu + jitter I), lower, column-major
+    void* LBc = nullptr;     // chol(B), lower, column-major
+    void* LBinv = nullptr;   // LB^-1 lower, column-major, strict upper zeroed
+    void* LBinvT = nullptr;  // its transpose (upper as col-major == rows of LB^-1 contiguous)
+    void* AAt = nullptr;     // A A^T (full symmetric)
+    void* Mtmp = nullptr;    // M x M scratch
+    void* Mtmp2 = nullptr;   // M x M scratch
+    void* Guf = nullptr;     // adjoint of Kuf, same layout as At (allocated on first gradient)
+    rocblas_int* info_dev = nullptr;
+    double trace_AAt = 0, sum_log_diag_LB = 0;
+    // work vectors (T): all length nloc unless noted
+    void *w_r = nullptr, *w_z = nullptr, *w_p = nullptr, *w_Ap = nullptr, *w_Kv = nullptr, *w_e = nullptr;
+    void* w_pfull = nullptr;       // [N] gathered p for single-shard solve
+    void *w_u = nullptr, *w_t = nullptr, *w_t2 = nullptr;  // [M]
+    void* kpart = nullptr;         // K_ff mat-vec partial row sums [jsplit][nloc]
+    size_t kpart_cap = 0;
+    void* tpart = nullptr;         // A^T t partial sums [msplit][nloc]
+    double* dotpart = nullptr;     // block partials for dots (double always) [DOTPART_CAP]
+    double* scal = nullptr;        // device scalars (double) [64]
+    double* gpart = nullptr;       // gradient partial buffers
+    size_t gpart_cap = 0;
+    double* gradbuf = nullptr;     // device packed gradient [GRAD_LEN]
+    // tunables
+    int kff_variant = 0, kff_jsplit = 0, kff_rows = 4;
+    std::string err;
+};
+
+#define DOTPART_CAP 8192
+
+#define HIP_CHECK(ctx, expr)                                                                         \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                          \
+            return CGLB_ERR_HIP;                                                                     \
+        }                                                                                            \
+    } while (0)
+
+#define BLAS_CHECK(ctx, expr)                                                                        \
+    do {                                                                                             \
+        rocblas_status _s = (expr);                                                                  \
+        if (_s != rocblas_status_success) {                                                          \
+            (ctx)->err = std::string(#expr) + ": rocblas status " + std::to_string((int)_s);         \
+            return CGLB_ERR_BLAS;                                                                    \
+        }                                                                                            \
+    } while (0)
+
+#define CGLB_TRY(expr)                 \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != CGLB_OK) return _rc; \
+    } while (0)
+
+static inline int cglb_fail(cglb_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+static inline int pad_dim(int d) {
+    const int sizes[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    for (int s : sizes)
+        if (d <= s) return s;
+    return -1;
+}
+
+// ---- launchers implemented in the kernel translation units (all enqueue on ctx->stream) ----------
+// kernels_prep.hip
+int launch_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out);
+int launch_kuf(cglb_ctx* c);  // At <- Kuf[:, rows] (unscaled by sigma)
+int launch_kuu(cglb_ctx* c);  // Lc <- Kuu + jitter I (full symmetric)
+// kernels_kff.hip
+int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
+int launch_cross_matvec(cglb_ctx* c, const void* Xs_new, const void* xa_new, int64_t n_new, const void* v_full, void* out);
+// kernels_vec.hip
+int launch_dot(cglb_ctx* c, const void* a, const void* b, int64_t n, double* out_slot);
+int launch_update_v_r(cglb_ctx* c, void* v, void* r, const void* p, const void* Ap, const double* rz, const double* pAp, int update_r);
+int launch_residual(cglb_ctx* c, void* r, const void* b, const void* Kv);
+int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart);
+int launch_gemv_u(cglb_ctx* c, const void* r_local, void* u_out);               // u = A_loc r
+int launch_tri_apply(cglb_ctx* c, const void* u, void* t_out);                  // t = LB^-T LB^-1 u
+int launch_precond_z(cglb_ctx* c, const void* r_local, const void* t, void* z_local, double* rz_slot);
+int launch_sub_scalar(cglb_ctx* c, void* out, const void* y_local, double mean, int64_t n);  // e = y - mean
+int launch_tri_clean(cglb_ctx* c, void* Mc, int keep_lower);   // zero the other strict triangle
+int launch_transpose(cglb_ctx* c, const void* src, void* dst); // M x M
+int launch_add_identity_trace(cglb_ctx* c, void* Mc, double* trace_slot);        // trace then += I
+int launch_sum_log_diag(cglb_ctx* c, const void* Mc, double* slot);
+int launch_symmetrize_lower(cglb_ctx* c, void* Mc);            // copy lower triangle to upper
+int launch_obj_scalars(cglb_ctx* c, const void* v_local, const void* r, const void* Kv, const void* w, double* sc8);
+// kernels_grad.hip
+int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double* out_dl /* dev double[D], overwritten */);
+int launch_grad_kuf(cglb_ctx* c, const void* cvec, const void* w_local, double* out /* packed gradient, accumulated */);
+int launch_grad_kuu(cglb_ctx* c, const void* Guu, const void* cvec, const void* mhalf_c, double* out);

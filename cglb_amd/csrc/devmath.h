@@ -1,0 +1,131 @@
+// Device-side arithmetic helpers for the streaming kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/cglb_hip.h"
+
+#define CGLB_LOG2E 1.4426950408889634073599246810019
+#define CGLB_LN2 0.69314718055994530941723212145818
+#define CGLB_SQRT3 1.7320508075688772935274463415059
+
+// 2^x for x <= 0 (x may be hugely negative -> 0).  fp64: no hardware transcendental on CDNA, so
+// round-to-nearest split x = n + r, |r| <= 1/2, degree-11 polynomial for 2^r (max rel. error 1.8e-16
+// including Horner round-off; fitted on Chebyshev nodes in extended precision), then ldexp.
+// 15 vector-fp64 instructions: rndne, add, 11 fma, cvt, ldexp.
+__device__ __forceinline__ double exp2_neg(double x) {
+    x = fmax(x, -1100.0);  // keeps the int conversion in range; 2^-1100 underflows to 0 anyway
+    const double n = __builtin_rint(x);
+    const double r = x - n;
+    double p = 0x1.e9ec94f24bf5bp-32;
+    p = __builtin_fma(p, r, 0x1.e6228f265d4ebp-28);
+    p = __builtin_fma(p, r, 0x1.b524ead100ee2p-24);
+    p = __builtin_fma(p, r, 0x1.62bfc2c4b4a97p-20);
+    p = __builtin_fma(p, r, 0x1.ffcbfc6e966e3p-17);
+    p = __builtin_fma(p, r, 0x1.430913112ed6ap-13);
+    p = __builtin_fma(p, r, 0x1.5d87fe78a3a63p-10);
+    p = __builtin_fma(p, r, 0x1.3b2ab6fb9f18fp-7);
+    p = __builtin_fma(p, r, 0x1.c6b08d704a0c9p-5);
+    p = __builtin_fma(p, r, 0x1.ebfbdff82c5afp-3);
+    p = __builtin_fma(p, r, 0x1.62e42fefa39efp-1);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+__device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// sqrt for x >= 0: hardware rsq seed (~2^-23 on fp64) + two coupled Goldschmidt steps + one residual
+// correction -> <= 1 ulp.  x == 0 returns 0.
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double xs = fmax(x, 1e-280);
+    double y = __builtin_amdgcn_rsq(xs);
+    double g = xs * y;
+    double h = 0.5 * y;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    const double d = __builtin_fma(-g, g, xs);
+    g = __builtin_fma(d, h, g);
+    return x > 0.0 ? g : 0.0;
+}
+__device__ __forceinline__ float sqrt_pos(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
+
+template <typename T> __device__ __forceinline__ T tfma(T a, T b, T c);
+template <> __device__ __forceinline__ double tfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float tfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <typename T> __device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
+template <typename T> __device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }
+
+// Kernel profile from the scaled operands.
+//   RBF:      xs = (x-c)/l*sqrt(log2 e), a = -|xs|^2/2      kappa = 2^(a_i + a_j + xs_i.xs_j)
+//   Matern32: xs = (x-c)/l*sqrt3*log2 e, a = |xs|^2          r' = sqrt(max(a_i+a_j-2 xs_i.xs_j,0)),
+//             kappa = (1 + r' ln2) 2^(-r')
+// `g` receives the gradient factor h/var (RBF: kappa; Matern32: 3*2^(-r')), see kernels_grad.hip.
+template <typename T, int KIND> __device__ __forceinline__ T kappa_from_gram(T ai, T aj, T dot) {
+    if (KIND == CGLB_RBF) {
+        T arg = tmin<T>(ai + aj + dot, T(0));
+        return exp2_neg(arg);
+    } else {
+        T d2 = tfma<T>(T(-2), dot, ai + aj);
+        T r = sqrt_pos(tmax<T>(d2, T(0)));
+        return tfma<T>(r, T(CGLB_LN2), T(1)) * exp2_neg(-r);
+    }
+}
+
+// Kernel profile from an exact scaled squared distance (direct differences; used off the N^2 path).
+//   d2s is in the scaled units above.
+template <typename T, int KIND> __device__ __forceinline__ T kappa_from_d2(T d2s) {
+    if (KIND == CGLB_RBF) {
+        return exp2_neg(T(-0.5) * d2s);
+    } else {
+        T r = sqrt_pos(d2s);
+        return tfma<T>(r, T(CGLB_LN2), T(1)) * exp2_neg(-r);
+    }
+}
+// gradient factor: dk/dl_d = var * hfac * delta_d^2 / l_d with delta in UNscaled-by-kscale units.
+template <typename T, int KIND> __device__ __forceinline__ T hfac_from_d2(T d2s) {
+    if (KIND == CGLB_RBF) {
+        return exp2_neg(T(-0.5) * d2s);
+    } else {
+        return T(3) * exp2_neg(-sqrt_pos(d2s));
+    }
+}
+
+// ---- reductions ------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Block sum of a double for blockDim.x <= 1024 (multiple of 64); result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double* smem /* >= 16 doubles */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) s += smem[i];
+    }
+    return s;
+}
+
+// Every thread of the block gets the (bitwise identical, fixed-order) sum of n device doubles.
+__device__ __forceinline__ double block_reduce_array(const double* __restrict__ a, int n, double* smem) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += a[i];
+    s = block_sum(s, smem);
+    __shared__ double bcast;
+    if (threadIdx.x == 0) bcast = s;
+    __syncthreads();
+    return bcast;
+}

@@ -1,0 +1,249 @@
+// K5 — gradient passes (what torch.autograd.grad(loss, variables) yields in
+// pytorch/optimizer.py:95-98 with v detached, models.py:257-274), written as explicit bilinear forms:
+//   grad_kff : sum_ij u_i (dK_ff/dl_d)_ij v_j                       (N^2 pairs, vector-fp64 bound)
+//   grad_kuf : sum_mn G[m][n] dK_uf[m][n]/d{l_d, var, z_m}          (M x N, streams the adjoint panel)
+// Direct differences are used here (the per-dimension delta^2 is needed anyway), so coincident points
+// contribute exactly 0 and the Matern-3/2 derivative needs no sqrt guard:
+//   dk/dl_d = var * h * delta_d^2 / l_d,  dk/dx1_d = -var * h * delta_d / l_d,
+//   delta_d = (x1_d - x2_d)/l_d,  h = kappa (RBF) | 3 exp(-sqrt3 r) (Matern-3/2).
+// Operands are the scaled ones of K1 (xs = (x-c)/l*kscale); the 1/(l_d kscale^2) factors are applied
+// in the finalize kernels.
+#include "devmath.h"
+#include "dispatch.h"
+
+// ---- N^2 pass ---------------------------------------------------------------------------------------
+// Thread owns R rows; column operand (xs_j, v_j) is wave-uniform (scalar loads).
+// part[(by * gridDim.x + bx) * DP + d] = sum_{i in block} u_i sum_{j in chunk} h_ij v_j (xs_id - xs_jd)^2
+template <typename T, int KIND, int DP, int R>
+__global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsRow, const T* __restrict__ u_local, int64_t nrows,
+                                                       const T* __restrict__ Xs, const T* __restrict__ v, int64_t N, int64_t jchunk,
+                                                       double* __restrict__ part) {
+    __shared__ double smem[16];
+    const int64_t rbase = (int64_t)blockIdx.x * (256 * R) + threadIdx.x;
+    T xi[R][DP], acc[R][DP], ui[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int64_t row = rbase + (int64_t)k * 256;
+        const int64_t rr = row < nrows ? row : nrows - 1;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            xi[k][d] = XsRow[rr * DP + d];
+            acc[k][d] = 0;
+        }
+        ui[k] = row < nrows ? u_local[rr] : T(0);
+    }
+    const int64_t j0 = (int64_t)blockIdx.y * jchunk;
+    const int64_t j1 = (j0 + jchunk < N) ? j0 + jchunk : N;
+    for (int64_t j = j0; j < j1; ++j) {
+        const T vj = v[j];
+        T xj[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            T sq[DP];
+            T d2 = 0;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const T df = xi[k][d] - xj[d];
+                sq[d] = df * df;
+                d2 += sq[d];
+            }
+            const T hv = hfac_from_d2<T, KIND>(d2) * vj;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) acc[k][d] = tfma<T>(hv, sq[d], acc[k][d]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) s += (double)ui[k] * (double)acc[k][d];
+        s = block_sum(s, smem);
+        if (threadIdx.x == 0) part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * DP + d] = s;
+    }
+}
+
+// out[d] += scale[d] * sum_b part[b*DP + d]   (one block per d)
+__global__ __launch_bounds__(256) void grad_dl_finalize_kernel(const double* __restrict__ part, int64_t nblk, int DP, int D,
+                                                               ScaleParams sp, double var, double* __restrict__ out, int accumulate) {
+    __shared__ double smem[16];
+    const int d = blockIdx.x;
+    if (d >= D) return;
+    double s = 0.0;
+    for (int64_t b = threadIdx.x; b < nblk; b += blockDim.x) s += part[b * DP + d];
+    s = block_sum(s, smem);
+    if (threadIdx.x == 0) {
+        const double val = s * var * sp.scale[d];  // sp.scale holds 1/(l_d kscale^2) here
+        out[d] = accumulate ? out[d] + val : val;
+    }
+}
+
+static int ensure_gpart(cglb_ctx* c, size_t need) {
+    if (need > c->gpart_cap) {
+        if (c->gpart) HIP_CHECK(c, hipFree(c->gpart));
+        c->gpart = nullptr;
+        HIP_CHECK(c, hipMalloc((void**)&c->gpart, need));
+        c->gpart_cap = need;
+    }
+    return CGLB_OK;
+}
+
+static inline double kscale_of(const cglb_ctx* c) { return (c->kind == CGLB_RBF) ? sqrt(CGLB_LOG2E) : CGLB_SQRT3 * CGLB_LOG2E; }
+
+// out_dl[d] (device double[D], overwritten) = sum_{i local, j} u_i dK_ij/dl_d v_j
+int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double* out_dl) {
+    ScaleParams sp;
+    const double ks = kscale_of(c);
+    for (int d = 0; d < CGLB_MAX_D; ++d) {
+        sp.center[d] = 0;
+        sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
+    }
+    if (c->nloc == 0) {
+        HIP_CHECK(c, hipMemsetAsync(out_dl, 0, sizeof(double) * c->D, c->stream));
+        return CGLB_OK;
+    }
+    const int R = c->Dp <= 8 ? 2 : 1;
+    const int64_t bx = (c->nloc + 256 * R - 1) / (256 * R);
+    int64_t jsplit = (8192 + bx - 1) / bx;
+    if (jsplit > 512) jsplit = 512;
+    if (jsplit > (c->N + 63) / 64) jsplit = (c->N + 63) / 64;
+    if (jsplit < 1) jsplit = 1;
+    const int64_t jchunk = (c->N + jsplit - 1) / jsplit;
+    jsplit = (c->N + jchunk - 1) / jchunk;
+    const int64_t nblk = bx * jsplit;
+    CGLB_TRY(ensure_gpart(c, (size_t)nblk * c->Dp * sizeof(double)));
+    dim3 grid((unsigned)bx, (unsigned)jsplit);
+#define GK_LAUNCH(RR)                                                                                                      \
+    hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR>), grid, dim3(256), 0, c->stream, (const T*)c->Xs + c->r0 * DP,      \
+                       (const T*)u_local, c->nloc, (const T*)c->Xs, (const T*)v_full, c->N, jchunk, c->gpart)
+    CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2); } else { GK_LAUNCH(1); });
+#undef GK_LAUNCH
+    CGLB_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(grad_dl_finalize_kernel, dim3(c->D), dim3(256), 0, c->stream, (const double*)c->gpart, nblk, c->Dp, c->D, sp,
+                       c->var, out_dl, 0);
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
+// ---- M x ncols pass over an adjoint panel --------------------------------------------------------------
+// grid (M, nsplit); block (m, s) handles columns [s*chunk,(s+1)*chunk) of row m.
+// G (adjoint, row m contiguous, ld = ldg) plus optional rank-1 term cvec[m]*wvec[n].
+// part[(m*nsplit+s)*(2*DP+1) + {0..DP-1: dl, DP..2DP-1: dz, 2DP: df}]
+template <typename T, int KIND, int DP>
+__global__ __launch_bounds__(256) void grad_panel_kernel(const T* __restrict__ G, int64_t ldg, const T* __restrict__ cvec,
+                                                         const T* __restrict__ wvec, const T* __restrict__ ZsRow,
+                                                         const T* __restrict__ XsCol, int64_t ncols, int64_t chunk,
+                                                         double* __restrict__ part) {
+    __shared__ double smem[16];
+    const int m = blockIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.y * chunk;
+    const int64_t n1 = (n0 + chunk < ncols) ? n0 + chunk : ncols;
+    T z[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) z[d] = ZsRow[(int64_t)m * DP + d];
+    const T cm = cvec ? cvec[m] : T(0);
+    double adl[DP], adz[DP], adf = 0.0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) { adl[d] = 0.0; adz[d] = 0.0; }
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += blockDim.x) {
+        T g = G[(int64_t)m * ldg + n];
+        if (cvec) g = tfma<T>(cm, wvec[n], g);
+        T df[DP], d2 = 0;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            df[d] = z[d] - XsCol[n * DP + d];
+            d2 = tfma<T>(df[d], df[d], d2);
+        }
+        const T kap = kappa_from_d2<T, KIND>(d2);
+        const T h = (KIND == CGLB_RBF) ? kap : hfac_from_d2<T, KIND>(d2);
+        const T W = g * h;
+        adf += (double)g * (double)kap;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            const T wd = W * df[d];
+            adz[d] += (double)wd;
+            adl[d] += (double)(wd * df[d]);
+        }
+    }
+    double* out = part + ((int64_t)m * gridDim.y + blockIdx.y) * (2 * DP + 1);
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        const double s = block_sum(adl[d], smem);
+        if (threadIdx.x == 0) out[d] = s;
+    }
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        const double s = block_sum(adz[d], smem);
+        if (threadIdx.x == 0) out[DP + d] = s;
+    }
+    const double s = block_sum(adf, smem);
+    if (threadIdx.x == 0) out[2 * DP] = s;
+}
+
+// Finalize: out = packed gradient (dl[D], dvar, dnoise, dmean, dZ[M*D]); accumulates into it.
+//   dl[d]   += var/(l_d ks^2) * sum_{m,s} adl
+//   dvar    += sum_{m,s} adf
+//   dZ[m,d] += -zfactor * var/(l_d ks) * sum_s adz
+__global__ __launch_bounds__(256) void grad_panel_finalize_kernel(const double* __restrict__ part, int M, int nsplit, int DP, int D,
+                                                                  ScaleParams sp, double var, double zfactor, double* __restrict__ out) {
+    __shared__ double smem[16];
+    const int W = 2 * DP + 1;
+    const int b = blockIdx.x;
+    if (b < D) {  // dl[b]
+        double s = 0.0;
+        for (int64_t k = threadIdx.x; k < (int64_t)M * nsplit; k += blockDim.x) s += part[k * W + b];
+        s = block_sum(s, smem);
+        if (threadIdx.x == 0) out[b] += s * var * sp.scale[b];
+    } else if (b == D) {  // dvar
+        double s = 0.0;
+        for (int64_t k = threadIdx.x; k < (int64_t)M * nsplit; k += blockDim.x) s += part[k * W + 2 * DP];
+        s = block_sum(s, smem);
+        if (threadIdx.x == 0) out[D] += s;
+    } else {  // dZ rows: blocks D+1 ... ; each thread one (m, d)
+        const int64_t idx = (int64_t)(b - D - 1) * blockDim.x + threadIdx.x;
+        if (idx < (int64_t)M * D) {
+            const int m = (int)(idx / D), d = (int)(idx % D);
+            double s = 0.0;
+            for (int k = 0; k < nsplit; ++k) s += part[((int64_t)m * nsplit + k) * W + DP + d];
+            out[D + 3 + idx] += -zfactor * var * sp.center[d] * s;  // sp.center holds 1/(l_d ks) here
+        }
+    }
+}
+
+static int grad_panel(cglb_ctx* c, const void* G, int64_t ldg, const void* cvec, const void* wvec, const void* XsCol, int64_t ncols,
+                      double zfactor, double* out) {
+    if (ncols == 0) return CGLB_OK;
+    ScaleParams sp;
+    const double ks = kscale_of(c);
+    for (int d = 0; d < CGLB_MAX_D; ++d) {
+        sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
+        sp.center[d] = d < c->D ? 1.0 / (c->ls[d] * ks) : 0.0;
+    }
+    int nsplit = 1;
+    while ((int64_t)c->M * nsplit < 2048 && nsplit < 64 && ncols / (nsplit * 2) >= 2048) nsplit *= 2;
+    const int64_t chunk = (ncols + nsplit - 1) / nsplit;
+    nsplit = (int)((ncols + chunk - 1) / chunk);
+    const int W = 2 * c->Dp + 1;
+    CGLB_TRY(ensure_gpart(c, (size_t)c->M * nsplit * W * sizeof(double)));
+    dim3 grid((unsigned)c->M, (unsigned)nsplit);
+    CGLB_DISPATCH_ALL(c, hipLaunchKernelGGL((grad_panel_kernel<T, KIND, DP>), grid, dim3(256), 0, c->stream, (const T*)G, ldg,
+                                            (const T*)cvec, (const T*)wvec, (const T*)c->Zs, (const T*)XsCol, ncols, chunk, c->gpart));
+    CGLB_LAUNCH_CHECK(c);
+    const int zblocks = (int)(((int64_t)c->M * c->D + 255) / 256);
+    hipLaunchKernelGGL(grad_panel_finalize_kernel, dim3(c->D + 1 + zblocks), dim3(256), 0, c->stream, (const double*)c->gpart, c->M,
+                       nsplit, c->Dp, c->D, sp, c->var, zfactor, out);
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
+// Kuf part: adjoint = c->Guf (+ cvec[m] * w_local[n]); columns = local rows of X.
+int launch_grad_kuf(cglb_ctx* c, const void* cvec, const void* w_local, double* out) {
+    return grad_panel(c, c->Guf, c->lda, cvec, w_local, (const char*)c->Xs + (size_t)c->r0 * c->Dp * c->esz, c->nloc, 1.0, out);
+}
+
+// Kuu part: adjoint = Guu (symmetric M x M) - c c^T/2 passed as rank-1 (cvec, wvec = -c/2); columns = Z.
+// z_m appears in row and column of K_uu, hence the factor 2 on dZ.
+int launch_grad_kuu(cglb_ctx* c, const void* Guu, const void* cvec, const void* mhalf_c, double* out) {
+    return grad_panel(c, Guu, c->M, cvec, mhalf_c, c->Zs, c->M, 2.0, out);
+}

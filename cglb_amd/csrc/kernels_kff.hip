@@ -1,0 +1,153 @@
+// K1 — implicit kernel mat-vec  out_i = var * sum_j kappa(x_i, x_j) p_j (+ noise p_i)
+// Reference seam: `A @ p` with A = kernel(x).add_diag(sigma^2)  (models.py:251-252;
+// conjugate_gradient.py:57,66,72).  K_ff is never materialised.
+//
+// Roofline: vector-fp64 ALU.  Algorithmic HBM traffic is N(D+2)w bytes per mat-vec against N^2 pair
+// evaluations, so the kernel is built around VALU issue, not bandwidth:
+//   * each lane owns R rows x_i (R*DP values + norm term in VGPRs for the whole launch);
+//   * the column operand (xs_j, a_j, p_j) is wave-uniform, so it is fetched with scalar loads into
+//     SGPRs and fed straight into v_fma_f64 as the scalar source: no VGPRs, no LDS traffic, no bank
+//     conflicts for the streamed side;
+//   * pair value by the Gram form (DP fma + 1 add), 2^x by rndne/add/11-fma/ldexp (devmath.h);
+//   * columns are split over blockIdx.y; partial row sums go to a [jsplit][nrows] slab and are
+//     combined in fixed order (bitwise reproducible, no atomics).
+#include "devmath.h"
+#include "dispatch.h"
+
+template <typename T, int KIND, int DP, int R>
+__global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ XsRow, const T* __restrict__ xaRow,
+                                                         int64_t nrows, const T* __restrict__ Xs,
+                                                         const T* __restrict__ xa, const T* __restrict__ p, int64_t N,
+                                                         int64_t jchunk, T* __restrict__ part) {
+    const int64_t rbase = (int64_t)blockIdx.x * (256 * R) + threadIdx.x;
+    T xi[R][DP], ai[R], acc[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        int64_t row = rbase + (int64_t)k * 256;
+        row = row < nrows ? row : nrows - 1;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xi[k][d] = XsRow[row * DP + d];
+        ai[k] = xaRow[row];
+        acc[k] = 0;
+    }
+    const int64_t j0 = (int64_t)blockIdx.y * jchunk;
+    const int64_t j1 = (j0 + jchunk < N) ? j0 + jchunk : N;
+#pragma unroll 2
+    for (int64_t j = j0; j < j1; ++j) {
+        const T aj = xa[j];
+        const T pj = p[j];
+        T xj[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            T dot = xi[k][0] * xj[0];
+#pragma unroll
+            for (int d = 1; d < DP; ++d) dot = tfma<T>(xi[k][d], xj[d], dot);
+            const T kap = kappa_from_gram<T, KIND>(ai[k], aj, dot);
+            acc[k] = tfma<T>(kap, pj, acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int64_t row = rbase + (int64_t)k * 256;
+        if (row < nrows) part[(int64_t)blockIdx.y * nrows + row] = acc[k];
+    }
+}
+
+// out[i] = var * sum_s part[s][i] + noise * pdiag[i];  optional block partials of pdiag[i]*out[i].
+template <typename T>
+__global__ __launch_bounds__(256) void kff_combine_kernel(const T* __restrict__ part, int jsplit, int64_t nrows, T var,
+                                                          T noise, const T* __restrict__ pdiag, T* __restrict__ out,
+                                                          double* __restrict__ dotpart) {
+    __shared__ double smem[16];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double contrib = 0.0;
+    if (i < nrows) {
+        T s = 0;
+        for (int js = 0; js < jsplit; ++js) s += part[(int64_t)js * nrows + i];
+        T o = var * s;
+        if (pdiag) {
+            o = tfma<T>(noise, pdiag[i], o);
+            contrib = (double)pdiag[i] * (double)o;
+        }
+        out[i] = o;
+    }
+    if (dotpart) {
+        const double bs = block_sum(contrib, smem);
+        if (threadIdx.x == 0) dotpart[blockIdx.x] = bs;
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_sum_kernel(const double* __restrict__ partials, int n, double* __restrict__ out) {
+    __shared__ double smem[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += partials[i];
+    s = block_sum(s, smem);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+static inline int rows_per_thread(const cglb_ctx* c) {
+    int r = c->kff_rows;
+    if (c->Dp > 16) r = 1;
+    else if (c->Dp > 8 && r > 2) r = 2;
+    if (r != 1 && r != 2 && r != 4) r = 4;
+    return r;
+}
+
+template <typename T, int KIND, int DP>
+static int kff_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrows, const T* p_full, T* out, const T* pdiag,
+                       T noise, double* pdot_slot) {
+    if (nrows == 0) return CGLB_OK;
+    const int R = rows_per_thread(c);
+    const int64_t bx = (nrows + 256 * R - 1) / (256 * R);
+    int64_t jsplit = c->kff_jsplit > 0 ? c->kff_jsplit : (8192 + bx - 1) / bx;
+    if (jsplit > 512) jsplit = 512;
+    if (jsplit > (c->N + 63) / 64) jsplit = (c->N + 63) / 64;
+    if (jsplit < 1) jsplit = 1;
+    int64_t jchunk = (c->N + jsplit - 1) / jsplit;
+    jchunk = (jchunk + 1) & ~(int64_t)1;
+    jsplit = (c->N + jchunk - 1) / jchunk;
+    const size_t need = (size_t)jsplit * nrows * sizeof(T);
+    if (need > c->kpart_cap) {
+        if (c->kpart) HIP_CHECK(c, hipFree(c->kpart));
+        c->kpart = nullptr;
+        HIP_CHECK(c, hipMalloc(&c->kpart, need));
+        c->kpart_cap = need;
+    }
+    dim3 grid((unsigned)bx, (unsigned)jsplit);
+    T* part = (T*)c->kpart;
+#define KFF_LAUNCH(RR)                                                                                              \
+    hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR>), grid, dim3(256), 0, c->stream, XsRow, xaRow, nrows,      \
+                       (const T*)c->Xs, (const T*)c->xa, p_full, c->N, jchunk, part)
+    if (R == 4) { if constexpr (DP <= 8) KFF_LAUNCH(4); else if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
+    else if (R == 2) { if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
+    else KFF_LAUNCH(1);
+#undef KFF_LAUNCH
+    CGLB_LAUNCH_CHECK(c);
+    const int cgrid = (int)((nrows + 255) / 256);
+    if (pdot_slot && cgrid > DOTPART_CAP) return cglb_fail(c, CGLB_ERR_BAD_ARG, "row shard too large for dot partials");
+    hipLaunchKernelGGL((kff_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)part, (int)jsplit, nrows,
+                       (T)c->var, noise, pdiag, out, pdot_slot ? c->dotpart : nullptr);
+    CGLB_LAUNCH_CHECK(c);
+    if (pdot_slot) {
+        hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, cgrid, pdot_slot);
+        CGLB_LAUNCH_CHECK(c);
+    }
+    return CGLB_OK;
+}
+
+// out_local = K_ff[rows,:] p + noise p[rows]; if pdot_slot != null also sum_i p_i out_i over local rows.
+int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot) {
+    CGLB_DISPATCH_ALL(c, return (kff_generic<T, KIND, DP>(c, (const T*)c->Xs + c->r0 * DP, (const T*)c->xa + c->r0, c->nloc,
+                                                          (const T*)p_full, (T*)out_local, (const T*)p_full + c->r0,
+                                                          (T)c->noise, pdot_slot)));
+    return CGLB_OK;
+}
+
+// out[i] = var * sum_j kappa(xnew_i, x_j) v_j over all N columns (no diagonal term).
+int launch_cross_matvec(cglb_ctx* c, const void* Xs_new, const void* xa_new, int64_t n_new, const void* v_full, void* out) {
+    CGLB_DISPATCH_ALL(c, return (kff_generic<T, KIND, DP>(c, (const T*)Xs_new, (const T*)xa_new, n_new, (const T*)v_full,
+                                                          (T*)out, (const T*)nullptr, (T)0, nullptr)));
+    return CGLB_OK;
+}

@@ -1,0 +1,146 @@
+/*
+ * cglb_hip.h — C ABI of the MI355X-native CGLB quadratic-term solver (libcglb_hip.so).
+ *
+ * The reference (awav/CGLB, pure Python) has no FFI; these entry points are what a binding for its
+ * hot path would call.  Each one cites the reference seam it stands in for (paths relative to the
+ * reference repo root).  See INTEGRATION.md for the ctypes stub that plugs them into cglb.backend.
+ *
+ * Conventions
+ *   - All array arguments are plain pointers; matrices are row-major; "dev" pointers are device
+ *     (HBM) addresses (e.g. torch.Tensor.data_ptr()), "host" pointers are ordinary host memory,
+ *     "any" may be either (copied with hipMemcpyDefault).  The caller owns every array it passes;
+ *     the library keeps no pointer past the call (set_data/set_hypers copy).
+ *   - Element type of vectors/matrices follows the ctx dtype (CGLB_F64 -> double, CGLB_F32 -> float);
+ *     hyper-parameters and returned scalars are always double.
+ *   - Every function returns 0 (CGLB_OK) or an error code; cglb_last_error() gives the text.
+ *   - One ctx = one GPU = one row shard [row_begin,row_end) of the N training rows.  With a single
+ *     shard (row_begin=0,row_end=N) the fused calls (cglb_pcg_solve, cglb_objective_and_grad) do the
+ *     whole job.  With several shards (one process per GPU) the host drives the cglb_shard_* phases
+ *     and performs the collectives (RCCL through torch.distributed) between them.
+ *   - Calls on one ctx are serialised by the caller (the reference is single-threaded Python with a
+ *     blocking sync per CG iteration, conjugate_gradient.py:80-81).  Work is enqueued on the HIP stream
+ *     given at creation; functions that return host scalars synchronise that stream, the others do not.
+ */
+#ifndef CGLB_HIP_H
+#define CGLB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cglb_ctx cglb_ctx;
+
+enum { CGLB_OK = 0, CGLB_ERR_BAD_ARG = 1, CGLB_ERR_NOT_PD = 2, CGLB_ERR_HIP = 3, CGLB_ERR_BLAS = 4, CGLB_ERR_STATE = 5 };
+enum { CGLB_RBF = 0, CGLB_MATERN32 = 1 };      /* config.py:72-81 SquaredExponentialConfig / Matern32Config */
+enum { CGLB_F64 = 0, CGLB_F32 = 1 };           /* pytorch/interface.py:94-104 set_default_float */
+
+/* Number of entries of the packed gradient: [dl_1..dl_D, d variance, d noise, d mean, dZ (M*D row-major)] */
+#define CGLB_GRAD_LEN(D, M) ((D) + 3 + (M) * (D))
+
+int cglb_version(void);
+
+/* Model + data container.  Stands in for CGLB(data, likelihood, kernel) built by
+ * pytorch/interface.py:315-323 (create_model for CGLBConfig) and models.py:54-68 (v_vec buffer).
+ * stream: a hipStream_t (0 = default stream).  device: HIP device ordinal. */
+int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t row_end, int d, int m,
+                    int dtype, int kernel_kind, int device, void* stream);
+int cglb_ctx_destroy(cglb_ctx* ctx);
+const char* cglb_last_error(const cglb_ctx* ctx); /* never NULL; ctx may be NULL (creation errors) */
+
+/* Training inputs (model.train_inputs / train_targets, pytorch/interface.py:318-322).
+ * X: any [n_total, d] (all rows: the column side of K_ff is replicated), y: any [n_total]. */
+int cglb_set_data(cglb_ctx* ctx, const void* X, const void* y);
+
+/* Constrained hyper-parameters: kernel lengthscales/outputscale, likelihood noise, ConstantMean,
+ * inducing points, Cholesky jitter (pytorch/interface.py:150-178 model_parameters;
+ * backend.py:77-79 jitter).  lengthscales: host double[d]; Z: any [m, d] of ctx dtype. */
+int cglb_set_hypers(cglb_ctx* ctx, const double* lengthscales, double variance, double noise, double mean,
+                    const void* Z, double jitter);
+
+/* ---- common terms: LowerBoundCG.logdet_and_quad_common_terms, models.py:176-213 ---------------- */
+/* single shard: L = chol(K_uu + jitter I), A = L^-1 K_uf / sigma, B = A A^T + I, LB = chol(B), tr(AA^T). */
+int cglb_setup(cglb_ctx* ctx);
+/* sharded: _local computes L, the column shard A[:, rows] and the partial A_loc A_loc^T into the buffer
+ * returned by cglb_aat_buffer (dev [m*m]); the host all-reduces that buffer; _finish does the rest. */
+int cglb_shard_setup_local(cglb_ctx* ctx);
+void* cglb_aat_buffer(cglb_ctx* ctx);
+int cglb_shard_setup_finish(cglb_ctx* ctx);
+/* logdet_estimator (models.py:215-244) value for the current common terms. */
+int cglb_logdet(cglb_ctx* ctx, double* logdet);
+
+/* ---- operator seam: `A @ p` with A = kernel(x).add_diag(sigma^2), models.py:251-252,
+ *      conjugate_gradient.py:57,66,72 -------------------------------------------------------------- */
+/* out[row_begin:row_end] = K_ff[rows, :] p + noise * p[rows].  p_full: dev [n_total]; out: dev [n_local]. */
+int cglb_matvec(cglb_ctx* ctx, const void* p_full, void* out_local);
+/* Rectangular kernel mat-vec  out[i] = sum_j k(xnew_i, x_j) v_j  (ksf @ v, models.py:320,334).
+ * xnew: any [n_new, d]; v_full: dev [n_total]; out: dev [n_new]. Sums over ALL n_total columns. */
+int cglb_cross_matvec(cglb_ctx* ctx, const void* xnew, int64_t n_new, const void* v_full, void* out);
+
+/* ---- preconditioner seam: NystromPreconditioner.__call__, conjugate_gradient.py:95-113 ------------ */
+/* single shard: z = (Q_ff + noise I)^-1 r, rz = r^T z.  r,z: dev [n]; rz: host. */
+int cglb_precond_apply(cglb_ctx* ctx, const void* r, void* z, double* rz);
+/* sharded: u_partial[m] = A_loc r_loc (host all-reduces u), then z_loc and the partial sum of rz. */
+int cglb_shard_precond_u(cglb_ctx* ctx, const void* r_local, void* u_partial /* dev [m] */);
+int cglb_shard_precond_z(cglb_ctx* ctx, const void* r_local, const void* u /* dev [m], reduced */,
+                         void* z_local, void* rz_partial /* dev [1] */);
+
+/* ---- vector primitives of the PCG loop (conjugate_gradient.py:67-75), for the sharded host loop ---- */
+/* dot: out[0] = sum_i a_i b_i over local rows (dev scalar, deterministic order). */
+int cglb_shard_dot(cglb_ctx* ctx, const void* a_local, const void* b_local, void* out /* dev [1] */);
+/* v += gamma p ; r -= gamma Ap  with gamma = rz / pAp read from device scalars (:67-68,:72). */
+int cglb_shard_update_v_r(cglb_ctx* ctx, void* v_local, void* r_local, const void* p_local, const void* Ap_local,
+                          const void* rz /* dev [1] */, const void* pAp /* dev [1] */, int update_r);
+/* r = b - Kv (restart / initial residual, :58,:72). */
+int cglb_shard_residual(cglb_ctx* ctx, void* r_local, const void* b_local, const void* Kv_local);
+/* p = z + p * (new_rz / rz)  or  p = z on restart (:75). */
+int cglb_shard_update_p(cglb_ctx* ctx, void* p_local, const void* z_local, const void* new_rz /* dev [1] */,
+                        const void* rz /* dev [1] */, int restart);
+
+/* ---- solver seam: ConjugateGradient.__call__, conjugate_gradient.py:41-86 (single shard) ---------- */
+/* Solves (K_ff + noise I) v = b warm-started at v_inout (overwritten with the solution; the Python shim
+ * clones first so the caller's tensor is not mutated, :55).  Stops when 1/2 r^T P r <= max_error or
+ * steps == max_cg_iter, predicate tested before every iteration (:65); exact-residual restart when
+ * i % restart_cg_iter == restart_cg_iter-1 (:70-75).  steps / half_rz mirror ConjugateGradientStats (:25-28). */
+int cglb_pcg_solve(cglb_ctx* ctx, const void* b /* dev [n] */, void* v_inout /* dev [n] */, double max_error,
+                   int max_cg_iter, int restart_cg_iter, int* steps, double* half_rz);
+
+/* ---- objective seam: LowerBoundCG.forward + quad_estimator, models.py:151-174, :246-286, and its
+ *      gradient as torch.autograd.grad yields it with v detached (pytorch/optimizer.py:95-98) -------- */
+/* Runs cglb_setup, (optionally) the PCG from v_inout with b = y - mean, the bound assembly and the
+ * gradient.  out4 = {bound, lower, upper, logdet} (host); grad: host double[CGLB_GRAD_LEN(d,m)] or NULL
+ * (value only).  v_inout: dev [n] — the persistent warm-start vector (models.py:59-72, :274). */
+int cglb_objective_and_grad(cglb_ctx* ctx, void* v_inout, int run_cg, double max_error, int max_cg_iter,
+                            int restart_cg_iter, double* out4, double* grad, int* steps, double* half_rz);
+
+/* sharded pieces of the same evaluation (host all-reduces between phases):
+ *   phase1: Kv = (K+sI) v (v_full gathered), r = e - Kv, u_partial = A_loc r              -> all-reduce u[m]
+ *   phase2: w = P r (local), partial scalars sc[8] and aw_partial = A_loc w               -> all-reduce sc[8], aw[m]
+ *   phase3: partial packed gradient (dev double[GRAD_LEN]); rank-replicated terms are added by the
+ *           shard with row_begin == 0 only                                               -> all-reduce grad
+ *   finish: bound/lower/upper from reduced sc (host). */
+int cglb_shard_obj_phase1(cglb_ctx* ctx, const void* v_full, void* u_partial);
+int cglb_shard_obj_phase2(cglb_ctx* ctx, const void* v_full, const void* u /* dev [m], reduced */, void* sc_partial /* dev double[8] */,
+                          void* aw_partial /* dev [m] */);
+int cglb_shard_obj_phase3(cglb_ctx* ctx, const void* v_full, const void* sc /* dev double[8], reduced */,
+                          const void* aw /* dev [m], reduced */, void* grad_partial /* dev double[GRAD_LEN] */);
+int cglb_shard_obj_finish(cglb_ctx* ctx, const void* sc /* dev double[8], reduced */, double* out4);
+
+/* ---- prediction seam: PredictCG.forward, models.py:307-354 (needs common terms + a solved v) ------ */
+/* f_mean, f_var: dev [n_new].  v_full: dev [n] solution at tolerance 1e-3 (models.py:291). single shard. */
+int cglb_predict(cglb_ctx* ctx, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var);
+
+/* ---- introspection / measurement ------------------------------------------------------------------ */
+/* Copy common-term matrices out (tests): which = 0:A [m,n_local] 1:L [m,m] lower 2:LB [m,m] lower; dst: any. */
+int cglb_get_matrix(cglb_ctx* ctx, int which, void* dst);
+/* Average duration (ms, HIP events on the ctx stream) of `reps` back-to-back launches of one kernel family:
+ * which = 0: K_ff mat-vec (dominant kernel), 1: preconditioner apply, 2: gradient bilinear pass. */
+int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
+/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" ...; returns CGLB_ERR_BAD_ARG if unknown. */
+int cglb_set_option(cglb_ctx* ctx, const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGLB_HIP_H */
