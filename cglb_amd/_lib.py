@@ -33,6 +33,8 @@ SIGNATURES = {
     "cglb_shard_setup_finish": (c_int, [c_void_p]),
     "cglb_logdet": (c_int, [c_void_p, POINTER(c_double)]),
     "cglb_matvec": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "cglb_matvec_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cglb_shard_rhs": (c_int, [c_void_p, c_void_p]),
     "cglb_cross_matvec": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cglb_precond_apply": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     "cglb_shard_precond_u": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -473,6 +473,20 @@ int cglb_matvec(cglb_ctx* c, const void* p_full, void* out_local) {
     return launch_kff_matvec(c, p_full, out_local, nullptr);
 }
 
+int cglb_matvec_dot(cglb_ctx* c, const void* p_full, void* out_local, void* pdot) {
+    if (!c || !p_full || !out_local || !pdot) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede matvec");
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_kff_matvec(c, p_full, out_local, (double*)pdot);
+}
+
+int cglb_shard_rhs(cglb_ctx* c, void* out_local) {
+    if (!c || !out_local) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede rhs");
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_sub_scalar(c, out_local, (const char*)c->y + (size_t)c->r0 * c->esz, c->mean, c->nloc);
+}
+
 int cglb_cross_matvec(cglb_ctx* c, const void* xnew, int64_t n_new, const void* v_full, void* out) {
     if (!c || !xnew || !v_full || !out || n_new < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
     if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede cross_matvec");

@@ -1,0 +1,244 @@
+"""Row-sharded CGLB evaluation: one process per GPU, collectives through torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference has no distributed code; this is new design.  Rank g owns the row block
+I_g of K_ff: slices of y, v, r, z, p, Ap and the column shard A[:, I_g] of the Nystrom panel; X, Z, L, LB
+and the hyper-parameters are replicated.  One PCG iteration (conjugate_gradient.py:65-81) exchanges
+
+    all-gather   p            N/G elements per rank   (every rank needs the full direction for K[I_g,:] p)
+    all-reduce   p^T A p      1 scalar
+    all-reduce   u = A r      M elements             (before the replicated small triangular products)
+    all-reduce   r^T P r      1 scalar               (stop test, every iteration, as the reference does)
+
+all latency-bound on xGMI.  The local arithmetic is behind `LocalOps`: in production that is
+`HipLocalOps` (the C ABI of libcglb_hip.so); the CPU tests inject an oracle-backed implementation to
+exercise this driver at world_size 2 over gloo.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+try:
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    dist = None
+
+
+def row_partition(n: int, world: int) -> Tuple[int, list]:
+    """Contiguous equal blocks of `per = ceil(n/world)` rows (the last ones may be short or empty)."""
+    per = (n + world - 1) // world
+    return per, [(min(g * per, n), min((g + 1) * per, n)) for g in range(world)]
+
+
+class Comm:
+    """The two collectives the path needs.  world == 1 -> no-ops."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.active = dist is not None and dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+
+    def allreduce(self, t: torch.Tensor) -> None:
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def allgather_inplace(self, buf: torch.Tensor, per: int) -> None:
+        """buf has world*per elements; rank g's slice buf[g*per:(g+1)*per] is valid on rank g."""
+        if self.world == 1:
+            return
+        mine = buf[self.rank * per:(self.rank + 1) * per]
+        try:
+            dist.all_gather_into_tensor(buf, mine.clone(), group=self.group)
+        except (RuntimeError, NotImplementedError):
+            chunks = [buf[g * per:(g + 1) * per] for g in range(self.world)]
+            dist.all_gather(chunks, mine.clone(), group=self.group)
+
+
+class LocalOps:
+    """What the sharded driver needs from one rank.  All tensors live on `device` with `dtype`; scalar
+    slots are float64 tensors of one element; *_full vectors have N elements, *_local have nloc."""
+
+    device: torch.device
+    dtype: torch.dtype
+    N: int
+    M: int
+    D: int
+    r0: int
+    r1: int
+
+    def setup_local(self): raise NotImplementedError
+    def aat_tensor(self) -> torch.Tensor: raise NotImplementedError
+    def setup_finish(self): raise NotImplementedError
+    def rhs(self, out_local): raise NotImplementedError
+    def matvec(self, p_full, out_local): raise NotImplementedError
+    def matvec_dot(self, p_full, out_local, pdot): raise NotImplementedError
+    def precond_u(self, r_local, u_out): raise NotImplementedError
+    def precond_z(self, r_local, u, z_local, rz_out): raise NotImplementedError
+    def update_v_r(self, v_local, r_local, p_local, Ap_local, rz, pAp, update_r: bool): raise NotImplementedError
+    def residual(self, r_local, b_local, Kv_local): raise NotImplementedError
+    def update_p(self, p_local, z_local, new_rz, rz, restart: bool): raise NotImplementedError
+    def obj_phase1(self, v_full, u_out): raise NotImplementedError
+    def obj_phase2(self, v_full, u, sc_out, aw_out): raise NotImplementedError
+    def obj_phase3(self, v_full, sc, aw, grad_out): raise NotImplementedError
+    def obj_finish(self, sc) -> Tuple[float, float, float, float]: raise NotImplementedError
+
+
+class HipLocalOps(LocalOps):
+    """LocalOps over the C ABI (cglb_shard_* entry points of include/cglb_hip.h)."""
+
+    def __init__(self, ctx):
+        from . import _lib
+        self._lib = _lib
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.h = ctx._ctx
+        self.device, self.dtype = ctx.device, ctx.dtype
+        self.N, self.M, self.D, self.r0, self.r1 = ctx.N, ctx.M, ctx.D, ctx.r0, ctx.r1
+
+    @staticmethod
+    def _p(t):
+        from ctypes import c_void_p
+        return c_void_p(t.data_ptr())
+
+    def _ck(self, rc):
+        self._lib.check(rc, self.h)
+
+    def setup_local(self): self.ctx.setup_local()
+    def aat_tensor(self): return self.ctx.aat_tensor()
+    def setup_finish(self): self.ctx.setup_finish()
+    def rhs(self, out_local): self._ck(self.lib.cglb_shard_rhs(self.h, self._p(out_local)))
+    def matvec(self, p_full, out_local): self._ck(self.lib.cglb_matvec(self.h, self._p(p_full), self._p(out_local)))
+    def matvec_dot(self, p_full, out_local, pdot): self._ck(self.lib.cglb_matvec_dot(self.h, self._p(p_full), self._p(out_local), self._p(pdot)))
+    def precond_u(self, r_local, u_out): self._ck(self.lib.cglb_shard_precond_u(self.h, self._p(r_local), self._p(u_out)))
+    def precond_z(self, r_local, u, z_local, rz_out): self._ck(self.lib.cglb_shard_precond_z(self.h, self._p(r_local), self._p(u), self._p(z_local), self._p(rz_out)))
+    def update_v_r(self, v_local, r_local, p_local, Ap_local, rz, pAp, update_r): self._ck(self.lib.cglb_shard_update_v_r(self.h, self._p(v_local), self._p(r_local), self._p(p_local), self._p(Ap_local), self._p(rz), self._p(pAp), int(update_r)))
+    def residual(self, r_local, b_local, Kv_local): self._ck(self.lib.cglb_shard_residual(self.h, self._p(r_local), self._p(b_local), self._p(Kv_local)))
+    def update_p(self, p_local, z_local, new_rz, rz, restart): self._ck(self.lib.cglb_shard_update_p(self.h, self._p(p_local), self._p(z_local), self._p(new_rz), self._p(rz), int(restart)))
+    def obj_phase1(self, v_full, u_out): self._ck(self.lib.cglb_shard_obj_phase1(self.h, self._p(v_full), self._p(u_out)))
+    def obj_phase2(self, v_full, u, sc_out, aw_out): self._ck(self.lib.cglb_shard_obj_phase2(self.h, self._p(v_full), self._p(u), self._p(sc_out), self._p(aw_out)))
+    def obj_phase3(self, v_full, sc, aw, grad_out): self._ck(self.lib.cglb_shard_obj_phase3(self.h, self._p(v_full), self._p(sc), self._p(aw), self._p(grad_out)))
+
+    def obj_finish(self, sc):
+        from ctypes import c_double
+        out4 = (c_double * 4)()
+        self._ck(self.lib.cglb_shard_obj_finish(self.h, self._p(sc), out4))
+        return out4[0], out4[1], out4[2], out4[3]
+
+
+@dataclass
+class ShardedResult:
+    bound: float
+    lower: float
+    upper: float
+    logdet: float
+    steps: int
+    residual_error: float
+    grad: Optional[np.ndarray]  # packed constrained-space gradient, identical on every rank
+
+
+class ShardedCGLB:
+    """Sharded objective (+gradient) evaluation.  Every rank calls the same methods in the same order."""
+
+    def __init__(self, ops: LocalOps, comm: Optional[Comm] = None):
+        self.ops = ops
+        self.comm = comm if comm is not None else Comm()
+        self.N, self.M, self.D = ops.N, ops.M, ops.D
+        self.per, parts = row_partition(self.N, self.comm.world)
+        r0, r1 = parts[self.comm.rank]
+        if (ops.r0, ops.r1) != (r0, r1):
+            raise ValueError(f"rank {self.comm.rank}: local ops own rows [{ops.r0},{ops.r1}) but the partition says [{r0},{r1})")
+        self.r0, self.r1, self.nloc = r0, r1, r1 - r0
+        dev, dt = ops.device, ops.dtype
+        G, per = self.comm.world, self.per
+        z = lambda n, d=dt: torch.zeros(max(n, 1), dtype=d, device=dev)
+        # gathered vectors (padded to G*per so that equal-sized all-gathers line up with row order)
+        self.vbuf, self.pbuf = z(G * per), z(G * per)
+        self.r, self.z, self.Ap, self.Kv, self.b = z(self.nloc), z(self.nloc), z(self.nloc), z(self.nloc), z(self.nloc)
+        self.u, self.aw = z(self.M), z(self.M)
+        self.rz, self.rz_new, self.pAp = z(1, torch.float64), z(1, torch.float64), z(1, torch.float64)
+        self.sc = z(8, torch.float64)
+        self.grad = z(self.D + 3 + self.M * self.D, torch.float64)
+
+    # views --------------------------------------------------------------------------------------------
+    def _own(self, buf):
+        return buf[self.comm.rank * self.per: self.comm.rank * self.per + self.nloc]
+
+    @property
+    def v_local(self):
+        """This rank's slice of the persistent warm-start vector (models.py:59-72)."""
+        return self._own(self.vbuf)
+
+    def v_full(self):
+        return self.vbuf[: self.N]
+
+    # common terms --------------------------------------------------------------------------------------
+    def setup(self):
+        """models.py:176-213 with B = I + sum_g A_g A_g^T (one all-reduce of M x M per evaluation)."""
+        self.ops.setup_local()
+        if self.comm.world > 1:
+            self.comm.allreduce(self.ops.aat_tensor())
+        self.ops.setup_finish()
+
+    def _precond(self, rz_out):
+        self.ops.precond_u(self.r, self.u)
+        self.comm.allreduce(self.u)
+        self.ops.precond_z(self.r, self.u, self.z, rz_out)
+        self.comm.allreduce(rz_out)
+
+    # PCG (conjugate_gradient.py:41-86) ------------------------------------------------------------------
+    def pcg(self, max_error=1.0, max_cg_iter=100, restart_cg_iter=40) -> Tuple[int, float]:
+        """Solves (K_ff + noise I) v = y - mean from the current v (in place).  Returns (steps, 1/2 r^T P r)."""
+        ops, comm, per = self.ops, self.comm, self.per
+        p_local, v_local = self._own(self.pbuf), self._own(self.vbuf)
+        ops.rhs(self.b)
+        comm.allgather_inplace(self.vbuf, per)
+        ops.matvec(self.v_full(), self.Kv)                      # :57
+        ops.residual(self.r, self.b, self.Kv)                   # :58
+        self._precond(self.rz)                                  # :59
+        ops.update_p(p_local, self.z, self.rz, self.rz, True)   # :61  p = z
+        comm.allgather_inplace(self.pbuf, per)
+        rz = float(self.rz.item())
+        i = 0
+        while 0.5 * rz > max_error and i < max_cg_iter:         # :65
+            ops.matvec_dot(self.pbuf[: self.N], self.Ap, self.pAp)   # :66-67
+            comm.allreduce(self.pAp)
+            restart = restart_cg_iter > 0 and (i % restart_cg_iter == restart_cg_iter - 1)  # :70
+            ops.update_v_r(v_local, self.r, p_local, self.Ap, self.rz, self.pAp, not restart)  # :68, :72
+            if restart:
+                comm.allgather_inplace(self.vbuf, per)
+                ops.matvec(self.v_full(), self.Kv)
+                ops.residual(self.r, self.b, self.Kv)
+            self._precond(self.rz_new)                          # :73
+            ops.update_p(p_local, self.z, self.rz_new, self.rz, restart)  # :75
+            self.rz.copy_(self.rz_new)                          # :76
+            comm.allgather_inplace(self.pbuf, per)
+            rz = float(self.rz.item())                          # host test of :65 (the sync of :80-81)
+            i += 1
+        return i, 0.5 * rz
+
+    # objective + gradient (models.py:151-174, :246-286; optimizer.py:95-98) -------------------------------
+    def objective_and_grad(self, run_cg=True, max_error=1.0, max_cg_iter=100, restart_cg_iter=40, with_grad=True) -> ShardedResult:
+        ops, comm = self.ops, self.comm
+        self.setup()
+        steps, half = 0, float("nan")
+        if run_cg:
+            steps, half = self.pcg(max_error, max_cg_iter, restart_cg_iter)
+        comm.allgather_inplace(self.vbuf, self.per)
+        v_full = self.v_full()
+        ops.obj_phase1(v_full, self.u)
+        comm.allreduce(self.u)
+        ops.obj_phase2(v_full, self.u, self.sc, self.aw)
+        comm.allreduce(self.sc)
+        grad = None
+        if with_grad:
+            comm.allreduce(self.aw)
+            ops.obj_phase3(v_full, self.sc, self.aw, self.grad)
+            comm.allreduce(self.grad)
+            grad = self.grad.detach().cpu().numpy().copy()
+        bound, lower, upper, logdet = ops.obj_finish(self.sc)
+        return ShardedResult(bound, lower, upper, logdet, steps, half, grad)

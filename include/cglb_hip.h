@@ -74,6 +74,10 @@ int cglb_logdet(cglb_ctx* ctx, double* logdet);
  *      conjugate_gradient.py:57,66,72 -------------------------------------------------------------- */
 /* out[row_begin:row_end] = K_ff[rows, :] p + noise * p[rows].  p_full: dev [n_total]; out: dev [n_local]. */
 int cglb_matvec(cglb_ctx* ctx, const void* p_full, void* out_local);
+/* same, and pdot[0] = sum over local rows of p_i * out_i  ((p * Ap).sum(), conjugate_gradient.py:67). pdot: dev double[1]. */
+int cglb_matvec_dot(cglb_ctx* ctx, const void* p_full, void* out_local, void* pdot);
+/* right-hand side of the solve: out_local = y[rows] - mean  (err, models.py:253-254). */
+int cglb_shard_rhs(cglb_ctx* ctx, void* out_local);
 /* Rectangular kernel mat-vec  out[i] = sum_j k(xnew_i, x_j) v_j  (ksf @ v, models.py:320,334).
  * xnew: any [n_new, d]; v_full: dev [n_total]; out: dev [n_new]. Sums over ALL n_total columns. */
 int cglb_cross_matvec(cglb_ctx* ctx, const void* xnew, int64_t n_new, const void* v_full, void* out);

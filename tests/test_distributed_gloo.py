@@ -1,0 +1,83 @@
+"""The row-sharded driver (cglb_amd/distributed.py) at world_size 2 over gloo on CPU, with oracle-backed local
+ops, against the single-process oracle.  Covers partitioning (ragged last block), the collective sequence of the
+PCG loop (incl. the restart all-gather) and the phased objective/gradient reduction."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden_hypers, load_golden
+from oracle import cglb_oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, name, max_error, max_iter, restart, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cglb_amd.distributed import Comm, ShardedCGLB, row_partition
+        from sharded_oracle_ops import OracleLocalOps
+        g = load_golden(name)
+        hyp = golden_hypers(g)
+        N = g["X"].shape[0]
+        per, parts = row_partition(N, world)
+        r0, r1 = parts[rank]
+        ops = OracleLocalOps(int(g["kind"]), g["X"], g["y"], hyp, r0, r1)
+        drv = ShardedCGLB(ops, Comm())
+        drv.v_local.copy_(torch.from_numpy(g["v0"][r0:r1]))
+        res = drv.objective_and_grad(True, max_error, max_iter, restart)
+        v_full = drv.v_full().numpy().copy()
+        if rank == 0:
+            q.put((res.bound, res.lower, res.upper, res.steps, res.residual_error, res.grad, v_full))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("rbf_d8_trained", 2), ("m32_d3_random", 2), ("rbf_d8_restart", 2), ("c1_snelson_like_m32", 3)])
+def test_sharded_driver_matches_single_process(name, world):
+    g = load_golden(name)
+    hyp = golden_hypers(g)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    args = (world, port, name, float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]), q)
+    procs = [ctx.Process(target=_worker, args=(r,) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bound, lower, upper, steps, half_rz, grad, v_full = out
+    ref = orc.objective(int(g["kind"]), g["X"], g["y"], hyp, g["v0"], True, float(g["max_error"]), int(g["max_cg_iter"]),
+                        int(g["restart_cg_iter"]))
+    assert abs(steps - ref.steps) <= (0 if ref.steps <= 40 else 1)
+    assert bound == pytest.approx(ref.bound, rel=1e-8)
+    assert bound == pytest.approx(float(g["bound"]), rel=1e-6)
+    # gradient: compare at the driver's own v (CG round-off aside, the formula must agree exactly)
+    refg = orc.objective(int(g["kind"]), g["X"], g["y"], hyp, v_full, run_cg=False, with_grad=True)
+    assert bound == pytest.approx(refg.bound, rel=1e-12)
+    D, M = g["X"].shape[1], hyp.Z.shape[0]
+    packed = np.concatenate([refg.grad["lengthscales"], [refg.grad["variance"], refg.grad["noise"], refg.grad["mean"]], refg.grad["Z"].reshape(-1)])
+    np.testing.assert_allclose(grad, packed, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(packed).max()))
+
+
+def test_row_partition_covers_all_rows():
+    from cglb_amd.distributed import row_partition
+    for n, w in [(10, 3), (7, 8), (100000, 8), (5, 1), (16, 4)]:
+        per, parts = row_partition(n, w)
+        assert parts[0][0] == 0 and parts[-1][1] == n and len(parts) == w
+        assert all(a1 == b0 for (_, a1), (b0, _) in zip(parts[:-1], parts[1:]))
+        assert all(0 <= b - a <= per for a, b in parts)

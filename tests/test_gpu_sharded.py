@@ -1,0 +1,95 @@
+"""Row-sharded driver over the HIP local ops: world_size 1 against the fused C path, and 2 ranks sharing the one
+GPU over gloo (same driver code as the RCCL run; only the backend string differs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import golden_hypers, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(g, row_range=None):
+    from cglb_amd.hip_context import HipContext
+    hyp = golden_hypers(g)
+    ctx = HipContext(g["X"], g["y"], hyp.Z.shape[0], int(g["kind"]), row_range=row_range)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, hyp.Z, hyp.jitter)
+    return ctx
+
+
+@pytest.mark.parametrize("name", ["rbf_d8_trained", "m32_d3_random", "rbf_d8_restart", "rbf_d8_warm"])
+def test_world1_driver_equals_fused_path(name):
+    from cglb_amd.distributed import HipLocalOps, ShardedCGLB
+    g = load_golden(name)
+    args = (float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+    ctx = _mk(g)
+    v = torch.from_numpy(g["v0"]).to(ctx.device).clone()
+    fused = ctx.objective_and_grad(v, True, *args)
+    ctx2 = _mk(g)
+    drv = ShardedCGLB(HipLocalOps(ctx2))
+    drv.v_local.copy_(torch.from_numpy(g["v0"]).to(ctx2.device))
+    res = drv.objective_and_grad(True, *args)
+    assert res.steps == fused.steps
+    assert res.bound == pytest.approx(fused.bound, rel=1e-12)
+    np.testing.assert_allclose(drv.v_full().cpu().numpy(), v.cpu().numpy(), rtol=0, atol=1e-11 * np.abs(v.cpu().numpy()).max())
+    D = g["X"].shape[1]
+    np.testing.assert_allclose(res.grad[:D], fused.grad["lengthscales"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(res.grad[D + 3:], fused.grad["Z"].reshape(-1), rtol=1e-9, atol=1e-10)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, name, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cglb_amd.distributed import Comm, HipLocalOps, ShardedCGLB, row_partition
+        g = load_golden(name)
+        torch.cuda.set_device(0)
+        per, parts = row_partition(g["X"].shape[0], world)
+        ctx = _mk(g, parts[rank])
+        drv = ShardedCGLB(HipLocalOps(ctx), Comm())
+        drv.v_local.copy_(torch.from_numpy(g["v0"][parts[rank][0]:parts[rank][1]]).to(ctx.device))
+        res = drv.objective_and_grad(True, float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+        if rank == 0:
+            q.put((res.bound, res.steps, res.grad))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["rbf_d8_trained", "m32_d3_random"])
+def test_two_ranks_on_one_gpu_over_gloo(name):
+    g = load_golden(name)
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    bound, steps, grad = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert steps == int(g["steps"])
+    assert bound == pytest.approx(float(g["bound"]), rel=1e-9)
+    # against the fused single-shard evaluation on the same GPU
+    ctx = _mk(g)
+    v = torch.from_numpy(g["v0"]).to(ctx.device).clone()
+    fused = ctx.objective_and_grad(v, True, float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+    D = g["X"].shape[1]
+    np.testing.assert_allclose(grad[:D], fused.grad["lengthscales"], rtol=1e-8, atol=1e-9)
+    assert grad[D] == pytest.approx(fused.grad["variance"], rel=1e-8, abs=1e-9)
+    assert grad[D + 1] == pytest.approx(fused.grad["noise"], rel=1e-8, abs=1e-9)
+    np.testing.assert_allclose(grad[D + 3:], fused.grad["Z"].reshape(-1), rtol=1e-8, atol=1e-9)
