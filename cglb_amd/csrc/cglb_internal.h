@@ -41,6 +41,8 @@ struct cglb_ctx {
     void* Mtmp = nullptr;    // M x M scratch
     void* Mtmp2 = nullptr;   // M x M scratch
     void* Guf = nullptr;     // adjoint of Kuf, same layout as At (allocated on first gradient)
+    void* slabs = nullptr;   // split-K partial A A^T slabs [nslab][M][M]
+    size_t slab_cap = 0;
     rocblas_int* info_dev = nullptr;
     double trace_AAt = 0, sum_log_diag_LB = 0;
     // work vectors (T): all length nloc unless noted
@@ -57,6 +59,7 @@ struct cglb_ctx {
     double* gradbuf = nullptr;     // device packed gradient [GRAD_LEN]
     // tunables
     int kff_variant = 0, kff_jsplit = 0, kff_rows = 4;
+    bool kff_skip_combine = false;  // timing only: launch the pair kernel without the slab combine
     std::string err;
 };
 

@@ -125,6 +125,7 @@ static int kff_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrow
     else KFF_LAUNCH(1);
 #undef KFF_LAUNCH
     CGLB_LAUNCH_CHECK(c);
+    if (c->kff_skip_combine) return CGLB_OK;
     const int cgrid = (int)((nrows + 255) / 256);
     if (pdot_slot && cgrid > DOTPART_CAP) return cglb_fail(c, CGLB_ERR_BAD_ARG, "row shard too large for dot partials");
     hipLaunchKernelGGL((kff_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)part, (int)jsplit, nrows,
