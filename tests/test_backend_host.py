@@ -1,0 +1,96 @@
+"""Host-side logic of the cglb.backend mirror that needs no GPU: config registries, inducing-point init,
+SciPy pack/unpack/assign, constraint transforms, logger keys."""
+import numpy as np
+import pytest
+import torch
+
+from cglb_amd.backend import config as cfg
+from cglb_amd.backend.callbacks import Logger, StopWatch
+from cglb_amd.backend.models import BaseKernel, GaussianLikelihood, ScaleKernel
+from cglb_amd.backend.optimizer import Scipy
+from oracle import cglb_oracle as orc
+
+
+def test_registries_match_reference_keys():
+    assert set(cfg.SGPR_CONFIGS) == {"sgpr", "cglb", "sgprn2m", "cglbn2m", "cglbnm2"}          # config.py:144-150
+    assert set(cfg.KERNEL_CONFIGS) == {"SquaredExponential", "Matern32", "mat32", "rbf"}         # config.py:152-158
+    assert set(cfg.INDUCING_VARIABLE_CONFIGS) == {"InducingVariable", "ConditionalVariance", "iv", "cv"}
+    c = cfg.CGLBConfig(kernel=cfg.Matern32Config(), inducing_variable=cfg.InducingVariableConfig(16))
+    assert (c.max_error, c.joint_optimization, c.vzero) == (1.0, False, False)                   # config.py:110-114
+    data = (np.zeros((5, 3)), np.zeros(5))
+    p = c.params(data)
+    assert p["noise_variance"] == 1.0 and callable(p["inducing_variable"])                       # config.py:102-107
+    assert cfg.Matern32Config().params(data)["lengthscales"].tolist() == [1.0, 1.0, 1.0]          # config.py:74-76
+    with pytest.raises(Exception):
+        c.max_error = 2.0  # frozen dataclass
+
+
+def test_greedy_conditional_variance_is_pivoted_cholesky():
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((200, 2))
+
+    def kfn(x1, x2=None, full_cov=False):
+        if not full_cov:
+            return np.ones(len(x1))
+        return orc.kernel_matrix("matern32", x1, x1 if x2 is None else x2, np.ones(2), 1.0)
+
+    Z = cfg.greedy_conditional_variance(X, 12, kfn)
+    K = orc.kernel_matrix("matern32", X, X, np.ones(2), 1.0)
+    idx = [int(np.where((X == z).all(1))[0][0]) for z in Z]
+    assert len(set(idx)) == 12
+    for m in range(1, 12):
+        S = idx[:m]
+        cond = np.diag(K) - np.einsum("ij,ij->j", K[S], np.linalg.solve(K[np.ix_(S, S)] + 1e-12 * np.eye(m), K[S]))
+        assert cond[idx[m]] >= cond.max() * (1 - 1e-9)
+
+
+def test_scipy_pack_unpack_assign_roundtrip():
+    a = torch.nn.Parameter(torch.arange(6, dtype=torch.float64).reshape(2, 3))
+    b = torch.nn.Parameter(torch.tensor(7.0, dtype=torch.float64))
+    packed = Scipy.pack((a, b))
+    assert packed.tolist() == [0, 1, 2, 3, 4, 5, 7]
+    vals = Scipy.unpack((a, b), packed * 2)
+    Scipy.assign((a, b), vals)
+    assert a.data.tolist() == [[0, 2, 4], [6, 8, 10]] and float(b.data) == 14.0
+    with pytest.raises(ValueError):
+        Scipy.assign((a, b), vals[:1])
+    # minimize a quadratic through the same (loss, flat grad) contract as optimizer.py:41-46
+    res = Scipy().minimize(lambda: ((a - 1.0) ** 2).sum() + (b + 2.0) ** 2, [a, b], options=dict(maxiter=50))
+    assert res.success and np.allclose(a.data.numpy(), 1.0, atol=1e-5) and abs(float(b.data) + 2.0) < 1e-5
+
+
+def test_constraints_match_gpytorch_conventions():
+    lik = GaussianLikelihood(lower_bound=1e-6)          # GreaterThan(1e-6), interface.py:269
+    lik.noise = 1.0
+    assert float(lik.noise) == pytest.approx(1.0, rel=1e-12)
+    assert float(torch.nn.functional.softplus(lik.noise_covar._noise.raw) + 1e-6) == pytest.approx(1.0, rel=1e-12)
+    with pytest.raises(ValueError):
+        lik.noise = 1e-7
+    k = ScaleKernel(BaseKernel("rbf", 3))
+    k.base_kernel.lengthscale = np.array([0.5, 1.0, 2.0])
+    k.outputscale = 0.3
+    assert k.base_kernel.lengthscale.shape == (1, 3)
+    np.testing.assert_allclose(k.base_kernel.lengthscale.detach().numpy()[0], [0.5, 1.0, 2.0], rtol=1e-12)
+    assert float(k.outputscale) == pytest.approx(0.3, rel=1e-12)
+
+
+def test_logger_keys_and_stopwatch():
+    calls = []
+    lg = Logger("/tmp/x", lambda: {"loss": 1.5, "cg/steps": 3, "junk": 0, "train/rmse": 0.1}, lambda: {".kernel.variance": 1.0, ".inducing_point": 2},
+                holdout_interval=2, include_feval_log=True, verbose=False)
+    lg.timer.start()
+    with lg.no_recording():
+        lg(0)
+        lg.log_for_feval(steps=1)
+    assert lg.logs == {} and lg.counter == 1
+    lg.counter = 0
+    for i in range(4):
+        lg.log_for_feval(steps=i, residual_error=0.1)
+        lg(i)
+    assert lg.logs["iteration"] == [0, 2]
+    assert set(lg.logs) >= {"iteration", "elapsed_time", "params", "loss", "cg/steps", "train/rmse", "steps-per-feval", "residual_error-per-feval"}
+    assert "junk" not in lg.logs and ".inducing_point" not in lg.logs["params"][0]
+    sw = StopWatch()
+    assert not sw.started()
+    sw.start(); sw.pause(); sw.resume()
+    assert sw.stop() >= 0.0 and not sw.started()

@@ -1,0 +1,167 @@
+"""The cglb.backend mirror end to end on the GPU: model creation through the config dispatch, autograd contract of the
+objective (optimizer.py:95-98), SciPy training loop, metrics, save/load, plug-in seams and error behaviour."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cglb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(N=300, D=3, seed=5):
+    X, y, _ = orc.synthetic_problem(N, D, 8, seed)
+    n = int(N * 2 / 3)
+    return (X[:n], y[:n]), (X[n:], y[n:])
+
+
+def _model(kernel="Matern32", M=16, data=None):
+    from cglb_amd.backend import BACKENDS, CGLBConfig, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS
+    be = BACKENDS["hip"]
+    be.configure_backend(logdir="/tmp/cglb_amd_test", keops=False)
+    be.set_default_float("fp64")
+    be.set_default_jitter("fp64")
+    train, test = data or _data()
+    cfg = CGLBConfig(kernel=KERNEL_CONFIGS[kernel](), inducing_variable=INDUCING_VARIABLE_CONFIGS["cv"](M))
+    return be, be.create_model(cfg, train), (train, test)
+
+
+def _hyp_of(model):
+    from cglb_amd.backend.models import get_cholesky_jitter
+    ls, var, noise, mean, Z = [t.detach().cpu().numpy() for t in model.hyper_tensors()]
+    return orc.Hypers(ls, float(var), float(noise), float(mean), Z, get_cholesky_jitter())
+
+
+@pytest.mark.parametrize("kernel,kind", [("Matern32", "matern32"), ("rbf", "rbf")])
+def test_objective_value_and_autograd_contract(kernel, kind):
+    from cglb_amd.backend.models import LowerBoundCG
+    be, model, (train, _) = _model(kernel)
+    params = be.model_parameters(model)
+    assert set(params) == {".likelihood.variance", ".mean_function.c", ".inducing_variable.Z", ".kernel.lengthscales", ".kernel.variance"}
+    assert params[".likelihood.variance"] == pytest.approx(1.0) and params[".kernel.variance"] == pytest.approx(1.0)  # config.py:74-76,:104
+    lb = LowerBoundCG(model)
+    loss = -lb(None)
+    hyp = _hyp_of(model)
+    ref = orc.objective(kind, train[0], train[1], hyp, np.zeros(len(train[1])), True, 1.0)
+    assert model.cg_stats.steps == ref.steps
+    assert float(loss) == pytest.approx(-ref.bound, rel=1e-10)
+    # gradient wrt RAW parameters == chain rule of the oracle's constrained gradient (softplus -> sigmoid)
+    plist = list(model.parameters())
+    grads = torch.autograd.grad(loss, plist)
+    v = model.v_vec.cpu().numpy().reshape(-1)
+    g = orc.objective(kind, train[0], train[1], hyp, v, run_cg=False, with_grad=True).grad
+    named = dict(model.named_parameters())
+    got = {n: gr for (n, _), gr in zip(model.named_parameters(), grads)}
+    sig = lambda raw: torch.sigmoid(raw).numpy()
+    np.testing.assert_allclose(got["likelihood.noise_covar._noise.raw"].numpy(), -g["noise"] * sig(named["likelihood.noise_covar._noise.raw"].detach()), rtol=1e-7)
+    np.testing.assert_allclose(got["mean_module.constant"].numpy(), -g["mean"], rtol=1e-6, atol=1e-9 * np.abs(v).sum())
+    np.testing.assert_allclose(got["covar_module.inducing_points"].numpy(), -g["Z"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(got["covar_module.base_kernel.base_kernel._lengthscale.raw"].numpy().reshape(-1),
+                               -g["lengthscales"] * sig(named["covar_module.base_kernel.base_kernel._lengthscale.raw"].detach()).reshape(-1), rtol=1e-7)
+    np.testing.assert_allclose(got["covar_module.base_kernel._outputscale.raw"].numpy(),
+                               -g["variance"] * sig(named["covar_module.base_kernel._outputscale.raw"].detach()), rtol=1e-7)
+
+
+def test_cache_flags_skip_cg_like_reference():
+    from cglb_amd.backend.models import LowerBoundCG
+    be, model, _ = _model()
+    lb = LowerBoundCG(model)
+    l1 = float(-lb(None))
+    steps1 = model.cg_stats.steps
+    assert steps1 > 0
+    cached = LowerBoundCG(model, use_cache=True, cached_v_vec_initial=True)   # interface.py:619-625
+    with torch.no_grad():
+        l2 = float(-cached(None))
+    assert l2 == pytest.approx(l1, rel=1e-12)
+    assert model.cg_stats.steps == steps1   # no CG ran
+    # warm start: second evaluation starts from the stored solution -> 0 or few steps
+    float(-lb(None))
+    assert model.cg_stats.steps <= steps1
+
+
+def test_training_loop_metrics_save_load(tmp_path):
+    from cglb_amd.backend.callbacks import Logger
+    be, model, data = _model("Matern32", M=12)
+    mfn = be.metrics_fn(model, data)
+    logger = Logger(str(tmp_path), mfn, lambda: be.model_parameters(model), holdout_interval=5, include_feval_log=True, verbose=False)
+    loss0 = mfn()["loss"] if False else None
+    from cglb_amd.backend.models import LowerBoundCG
+    l_init = float(-LowerBoundCG(model)(None))
+    results = be.optimize(model, data, 25, logger, "scipy")
+    assert sum(r.nit for r in results) <= 25 + 3
+    m = mfn()
+    assert set(m) == {"cg/steps", "cg/error", "loss", "train/rmse", "test/rmse", "train/nlpd", "test/nlpd"}
+    assert m["loss"] < l_init - 1.0            # the bound improved
+    assert m["test/rmse"] < 0.9                # better than predicting the mean of z-normalised targets
+    assert {"loss", "cg/steps", "cg/error", "steps-per-feval", "residual_error-per-feval", "elapsed_time", "params", "iteration"} <= set(logger.logs)
+    be.save(model, str(tmp_path))
+    saved = json.load(open(os.path.join(tmp_path, "model.json")))
+    assert set(saved) == set(be.model_parameters(model))
+    be2, model2, _ = _model("Matern32", M=12, data=data)
+    be2.load(model2, os.path.join(tmp_path, "model.json"))
+    for k, v in be.model_parameters(model).items():
+        np.testing.assert_allclose(be2.model_parameters(model2)[k], v, rtol=1e-10, atol=1e-12)
+
+
+def test_predict_matches_oracle_and_errors():
+    from cglb_amd.backend.models import LowerBoundCG, PredictCG
+    be, model, (train, test) = _model("rbf", M=16)
+    float(-LowerBoundCG(model)(None))
+    hyp = _hyp_of(model)
+    pred = PredictCG(model)
+    f_mean, f_var = pred(torch.as_tensor(test[0]))
+    ref_mean, ref_var, _, st = orc.predict("rbf", train[0], train[1], hyp, model.v_vec.cpu().numpy().reshape(-1), test[0], 1e-3)
+    assert f_mean.shape == (len(test[1]), 1) and f_var.shape == f_mean.shape
+    np.testing.assert_allclose(f_mean.cpu().numpy().reshape(-1), ref_mean, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(f_var.cpu().numpy().reshape(-1), ref_var, rtol=1e-7, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        pred(torch.as_tensor(test[0]), full_cov=True)       # models.py:311-314
+    with pytest.raises(ValueError):
+        LowerBoundCG(object())                              # models.py:112-113
+
+
+def test_solver_and_preconditioner_seams():
+    """cg_opt is any callable (A, b, v, precond) -> (v, stats) (models.py:266-271); A only needs `@`."""
+    from cglb_amd.backend.conjugate_gradient import ConjugateGradient, ConjugateGradientStats, KernelOperator, NystromPreconditioner
+    from cglb_amd.backend.models import LowerBoundCG
+    be, model, (train, _) = _model("rbf", M=16)
+    seen = {}
+
+    class MyCG:
+        """A foreign solver written against the seam: plain PCG in terms of `A @ p` and `precond(r)` only."""
+        def __call__(self, A, b, v, precond):
+            v = v.clone()
+            r = b - A @ v
+            z, rz = precond(r)
+            p = z
+            i = 0
+            while 0.5 * float(rz) > 1.0 and i < 100:
+                Ap = A @ p
+                gamma = float(rz) / float((p * Ap).sum())
+                v += gamma * p
+                r = r - gamma * Ap
+                z, new_rz = precond(r)
+                p = z + p * float(new_rz) / float(rz)
+                rz = new_rz
+                i += 1
+            seen["steps"] = i
+            return v, ConjugateGradientStats(i, 0.5 * rz)
+
+    loss_plugin = float(-LowerBoundCG(model, cg_opt=MyCG())(None))
+    v_plugin = model.v_vec.clone()
+    model.v_vec.zero_()
+    loss_fused = float(-LowerBoundCG(model)(None))
+    assert seen["steps"] == model.cg_stats.steps
+    assert loss_plugin == pytest.approx(loss_fused, rel=1e-10)
+    np.testing.assert_allclose(v_plugin.cpu().numpy(), model.v_vec.cpu().numpy(), rtol=0, atol=1e-9 * float(v_plugin.abs().max()))
+    # the reference solver object must not mutate its v argument (conjugate_gradient.py:55)
+    hip = model.hip
+    v0 = torch.zeros(hip.N, 1, dtype=torch.float64, device=hip.device)
+    b = (hip.y - 0.0).reshape(-1, 1)
+    vout, stats = ConjugateGradient()(KernelOperator(hip), b, v0, NystromPreconditioner(hip))
+    assert float(v0.abs().max()) == 0.0 and vout.shape == v0.shape and isinstance(stats.steps, int)
+    with pytest.raises(TypeError):
+        ConjugateGradient()(torch.eye(hip.N, dtype=torch.float64), b, v0, NystromPreconditioner(hip))
