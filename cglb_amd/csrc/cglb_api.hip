@@ -458,6 +458,12 @@ int cglb_set_data(cglb_ctx* c, const void* X, const void* y) {
         for (int d = 0; d < c->D; ++d)
             c->xmean[d] += c->dtype == CGLB_F64 ? ((const double*)host.data())[i * c->D + d] : (double)((const float*)host.data())[i * c->D + d];
     for (int d = 0; d < c->D; ++d) c->xmean[d] /= (double)c->N;
+    for (int d = 0; d < c->D; ++d) c->xrange[d] = 0.0;
+    for (int64_t i = 0; i < c->N; ++i)
+        for (int d = 0; d < c->D; ++d) {
+            const double x = c->dtype == CGLB_F64 ? ((const double*)host.data())[i * c->D + d] : (double)((const float*)host.data())[i * c->D + d];
+            c->xrange[d] = std::fmax(c->xrange[d], std::fabs(x - c->xmean[d]));
+        }
     c->have_data = true;
     c->have_local = c->have_terms = false;
     return CGLB_OK;
@@ -474,6 +480,12 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
     c->var = variance; c->noise = noise; c->mean = mean; c->jitter = jitter;
     HIP_CHECK(c, hipMemcpyAsync(c->Z, Z, (size_t)c->M * c->D * c->esz, hipMemcpyDefault, c->stream));
     c->have_hypers = true;
+    {   // bound on |a_i + a_j + xs_i.xs_j| <= 2 max|xs|^2 ; the unclamped 2^x of the hot loops needs it < 2^30
+        const double ks = (c->kind == CGLB_RBF) ? std::sqrt(CGLB_LOG2E) : CGLB_SQRT3 * CGLB_LOG2E;
+        double s2 = 0.0;
+        for (int d = 0; d < c->D; ++d) { const double v = c->xrange[d] * ks / c->ls[d]; s2 += v * v; }
+        c->exp_clamp = !(2.0 * s2 < 1.0e9);
+    }
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
     CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zs, c->za));
     c->have_local = c->have_terms = false;

@@ -26,6 +26,7 @@ struct cglb_ctx {
     // raw data (element type T)
     void *X = nullptr, *y = nullptr, *Z = nullptr;
     double xmean[CGLB_MAX_D] = {0};  // column means of X (centre for the Gram form)
+    double xrange[CGLB_MAX_D] = {0}; // max |x - mean| per column (bounds the exponent range of the hot loops)
     // hypers (host)
     double ls[CGLB_MAX_D] = {0};
     double var = 1, noise = 1, mean = 0, jitter = 1e-6;
@@ -59,6 +60,7 @@ struct cglb_ctx {
     double* gradbuf = nullptr;     // device packed gradient [GRAD_LEN]
     // tunables
     int kff_variant = 0, kff_jsplit = 0, kff_rows = 4;
+    bool exp_clamp = false;         // scaled operands so large that 2^x needs the range clamp (set by set_hypers)
     bool kff_skip_combine = false;  // timing only: launch the pair kernel without the slab combine
     std::string err;
 };

@@ -14,7 +14,7 @@
 #include "devmath.h"
 #include "dispatch.h"
 
-template <typename T, int KIND, int DP, int R>
+template <typename T, int KIND, int DP, int R, bool CLAMP>
 __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ XsRow, const T* __restrict__ xaRow,
                                                          int64_t nrows, const T* __restrict__ Xs,
                                                          const T* __restrict__ xa, const T* __restrict__ p, int64_t N,
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ X
         row = row < nrows ? row : nrows - 1;
 #pragma unroll
         for (int d = 0; d < DP; ++d) xi[k][d] = XsRow[row * DP + d];
-        ai[k] = xaRow[row];
+        ai[k] = (KIND == CGLB_RBF) ? xaRow[row] : T(-0.5) * xaRow[row];  // seed of the Gram chain
         acc[k] = 0;
     }
     const int64_t j0 = (int64_t)blockIdx.y * jchunk;
@@ -41,10 +41,10 @@ __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ X
         for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            T dot = xi[k][0] * xj[0];
+            T gram = ai[k];
 #pragma unroll
-            for (int d = 1; d < DP; ++d) dot = tfma<T>(xi[k][d], xj[d], dot);
-            const T kap = kappa_from_gram<T, KIND>(ai[k], aj, dot);
+            for (int d = 0; d < DP; ++d) gram = tfma<T>(xi[k][d], xj[d], gram);
+            const T kap = kappa_from_gram<T, KIND, CLAMP>(gram, aj);
             acc[k] = tfma<T>(kap, pj, acc[k]);
         }
     }
@@ -117,9 +117,15 @@ static int kff_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrow
     }
     dim3 grid((unsigned)bx, (unsigned)jsplit);
     T* part = (T*)c->kpart;
-#define KFF_LAUNCH(RR)                                                                                              \
-    hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR>), grid, dim3(256), 0, c->stream, XsRow, xaRow, nrows,      \
-                       (const T*)c->Xs, (const T*)c->xa, p_full, c->N, jchunk, part)
+#define KFF_LAUNCH(RR)                                                                                               \
+    do {                                                                                                             \
+        if (c->exp_clamp)                                                                                            \
+            hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, true>), grid, dim3(256), 0, c->stream, XsRow,      \
+                               xaRow, nrows, (const T*)c->Xs, (const T*)c->xa, p_full, c->N, jchunk, part);          \
+        else                                                                                                         \
+            hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, false>), grid, dim3(256), 0, c->stream, XsRow,     \
+                               xaRow, nrows, (const T*)c->Xs, (const T*)c->xa, p_full, c->N, jchunk, part);          \
+    } while (0)
     if (R == 4) { if constexpr (DP <= 8) KFF_LAUNCH(4); else if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
     else if (R == 2) { if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
     else KFF_LAUNCH(1);
@@ -148,7 +154,12 @@ int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* 
 
 // out[i] = var * sum_j kappa(xnew_i, x_j) v_j over all N columns (no diagonal term).
 int launch_cross_matvec(cglb_ctx* c, const void* Xs_new, const void* xa_new, int64_t n_new, const void* v_full, void* out) {
-    CGLB_DISPATCH_ALL(c, return (kff_generic<T, KIND, DP>(c, (const T*)Xs_new, (const T*)xa_new, n_new, (const T*)v_full,
-                                                          (T*)out, (const T*)nullptr, (T)0, nullptr)));
-    return CGLB_OK;
+    // new points may lie far outside the training range: always take the range-clamped 2^x here
+    const bool saved = c->exp_clamp;
+    c->exp_clamp = true;
+    int rc = CGLB_OK;
+    CGLB_DISPATCH_ALL(c, rc = (kff_generic<T, KIND, DP>(c, (const T*)Xs_new, (const T*)xa_new, n_new, (const T*)v_full,
+                                                        (T*)out, (const T*)nullptr, (T)0, nullptr)));
+    c->exp_clamp = saved;
+    return rc;
 }
