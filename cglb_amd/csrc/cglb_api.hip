@@ -427,7 +427,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
-                    c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs};
+                    c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->blas) (void)rocblas_destroy_handle(c->blas);
     delete c;
@@ -439,6 +439,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "kff_variant")) c->kff_variant = (int)value;
     else if (!strcmp(name, "kff_jsplit")) c->kff_jsplit = (int)value;
     else if (!strcmp(name, "kff_rows")) c->kff_rows = (int)value;
+    else if (!strcmp(name, "sym_chunk")) c->sym_chunk_opt = value;
     else return cglb_fail(c, CGLB_ERR_BAD_ARG, std::string("unknown option ") + name);
     return CGLB_OK;
 }
@@ -488,6 +489,7 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
     }
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
     CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zs, c->za));
+    CGLB_TRY(launch_frag_prep(c));
     c->have_local = c->have_terms = false;
     return CGLB_OK;
 }

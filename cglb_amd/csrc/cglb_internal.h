@@ -42,6 +42,11 @@ struct cglb_ctx {
     void* Mtmp = nullptr;    // M x M scratch
     void* Mtmp2 = nullptr;   // M x M scratch
     void* Guf = nullptr;     // adjoint of Kuf, same layout as At (allocated on first gradient)
+    void *fragA = nullptr, *fragB = nullptr;  // MFMA-ordered augmented operands (kernels_kff_mfma.hip)
+    size_t frag_cap = 0;
+    void* sym_items = nullptr;       // work list (row block, column chunk) of the symmetric mat-vec
+    int64_t sym_n = -1, sym_chunk = 0, sym_chunk_opt = 0;
+    int sym_rbrows = 0, sym_nitems = 0;
     void* slabs = nullptr;   // split-K partial A A^T slabs [nslab][M][M]
     size_t slab_cap = 0;
     rocblas_int* info_dev = nullptr;
@@ -59,7 +64,7 @@ struct cglb_ctx {
     size_t gpart_cap = 0;
     double* gradbuf = nullptr;     // device packed gradient [GRAD_LEN]
     // tunables
-    int kff_variant = 0, kff_jsplit = 0, kff_rows = 4;
+    int kff_variant = 2, kff_jsplit = 0, kff_rows = 4;  // 0 plain, 1 matrix-pipe Gram (fp64), 2 symmetric (default)
     bool exp_clamp = false;         // scaled operands so large that 2^x needs the range clamp (set by set_hypers)
     bool kff_skip_combine = false;  // timing only: launch the pair kernel without the slab combine
     std::string err;
@@ -110,6 +115,10 @@ int launch_kuf(cglb_ctx* c);  // At <- Kuf[:, rows] (unscaled by sigma)
 int launch_kuu(cglb_ctx* c);  // Lc <- Kuu + jitter I (full symmetric)
 // kernels_kff.hip
 int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
+int launch_frag_prep(cglb_ctx* c);
+int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
+int launch_kff_plain_range(cglb_ctx* c, const void* p_full, int64_t col0, int64_t col1, void* part, int64_t* nslots);
+int launch_kff_mfma_pairs(cglb_ctx* c, const double* p_full, int64_t* jsplit_out);
 int launch_cross_matvec(cglb_ctx* c, const void* Xs_new, const void* xa_new, int64_t n_new, const void* v_full, void* out);
 // kernels_vec.hip
 int launch_dot(cglb_ctx* c, const void* a, const void* b, int64_t n, double* out_slot);

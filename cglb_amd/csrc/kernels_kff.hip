@@ -17,8 +17,8 @@
 template <typename T, int KIND, int DP, int R, bool CLAMP>
 __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ XsRow, const T* __restrict__ xaRow,
                                                          int64_t nrows, const T* __restrict__ Xs,
-                                                         const T* __restrict__ xa, const T* __restrict__ p, int64_t N,
-                                                         int64_t jchunk, T* __restrict__ part) {
+                                                         const T* __restrict__ xa, const T* __restrict__ p, int64_t col0,
+                                                         int64_t col1, int64_t jchunk, T* __restrict__ part) {
     const int64_t rbase = (int64_t)blockIdx.x * (256 * R) + threadIdx.x;
     T xi[R][DP], ai[R], acc[R];
 #pragma unroll
@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ X
         ai[k] = (KIND == CGLB_RBF) ? xaRow[row] : T(-0.5) * xaRow[row];  // seed of the Gram chain
         acc[k] = 0;
     }
-    const int64_t j0 = (int64_t)blockIdx.y * jchunk;
-    const int64_t j1 = (j0 + jchunk < N) ? j0 + jchunk : N;
+    const int64_t j0 = col0 + (int64_t)blockIdx.y * jchunk;
+    const int64_t j1 = (j0 + jchunk < col1) ? j0 + jchunk : col1;
 #pragma unroll 2
     for (int64_t j = j0; j < j1; ++j) {
         const T aj = xa[j];
@@ -87,54 +87,13 @@ __global__ __launch_bounds__(256) void finalize_sum_kernel(const double* __restr
     if (threadIdx.x == 0) out[0] = s;
 }
 
-static inline int rows_per_thread(const cglb_ctx* c) {
-    int r = c->kff_rows;
-    if (c->Dp > 16) r = 1;
-    else if (c->Dp > 8 && r > 2) r = 2;
-    if (r != 1 && r != 2 && r != 4) r = 4;
-    return r;
-}
-
-template <typename T, int KIND, int DP>
-static int kff_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrows, const T* p_full, T* out, const T* pdiag,
-                       T noise, double* pdot_slot) {
-    if (nrows == 0) return CGLB_OK;
-    const int R = rows_per_thread(c);
-    const int64_t bx = (nrows + 256 * R - 1) / (256 * R);
-    int64_t jsplit = c->kff_jsplit > 0 ? c->kff_jsplit : (8192 + bx - 1) / bx;
-    if (jsplit > 512) jsplit = 512;
-    if (jsplit > (c->N + 63) / 64) jsplit = (c->N + 63) / 64;
-    if (jsplit < 1) jsplit = 1;
-    int64_t jchunk = (c->N + jsplit - 1) / jsplit;
-    jchunk = (jchunk + 1) & ~(int64_t)1;
-    jsplit = (c->N + jchunk - 1) / jchunk;
-    const size_t need = (size_t)jsplit * nrows * sizeof(T);
-    if (need > c->kpart_cap) {
-        if (c->kpart) HIP_CHECK(c, hipFree(c->kpart));
-        c->kpart = nullptr;
-        HIP_CHECK(c, hipMalloc(&c->kpart, need));
-        c->kpart_cap = need;
-    }
-    dim3 grid((unsigned)bx, (unsigned)jsplit);
-    T* part = (T*)c->kpart;
-#define KFF_LAUNCH(RR)                                                                                               \
-    do {                                                                                                             \
-        if (c->exp_clamp)                                                                                            \
-            hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, true>), grid, dim3(256), 0, c->stream, XsRow,      \
-                               xaRow, nrows, (const T*)c->Xs, (const T*)c->xa, p_full, c->N, jchunk, part);          \
-        else                                                                                                         \
-            hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, false>), grid, dim3(256), 0, c->stream, XsRow,     \
-                               xaRow, nrows, (const T*)c->Xs, (const T*)c->xa, p_full, c->N, jchunk, part);          \
-    } while (0)
-    if (R == 4) { if constexpr (DP <= 8) KFF_LAUNCH(4); else if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
-    else if (R == 2) { if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
-    else KFF_LAUNCH(1);
-#undef KFF_LAUNCH
-    CGLB_LAUNCH_CHECK(c);
+// fixed-order combine of the partial slab c->kpart [jsplit][nrows] (+ noise p, + optional p.out partials)
+template <typename T>
+static int kff_combine(cglb_ctx* c, int64_t jsplit, int64_t nrows, T* out, const T* pdiag, T noise, double* pdot_slot) {
     if (c->kff_skip_combine) return CGLB_OK;
     const int cgrid = (int)((nrows + 255) / 256);
     if (pdot_slot && cgrid > DOTPART_CAP) return cglb_fail(c, CGLB_ERR_BAD_ARG, "row shard too large for dot partials");
-    hipLaunchKernelGGL((kff_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)part, (int)jsplit, nrows,
+    hipLaunchKernelGGL((kff_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)c->kpart, (int)jsplit, nrows,
                        (T)c->var, noise, pdiag, out, pdot_slot ? c->dotpart : nullptr);
     CGLB_LAUNCH_CHECK(c);
     if (pdot_slot) {
@@ -144,8 +103,80 @@ static int kff_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrow
     return CGLB_OK;
 }
 
+static inline int rows_per_thread(const cglb_ctx* c) {
+    int r = c->kff_rows;
+    if (c->Dp > 16) r = 1;
+    else if (c->Dp > 8 && r > 2) r = 2;
+    if (r != 1 && r != 2 && r != 4) r = 4;
+    return r;
+}
+
+// Launches the plain pair kernel for rows (XsRow, xaRow, nrows) against columns [col0, col1) into `part` ([slots][nrows]).
+template <typename T, int KIND, int DP>
+static int kff_pairs_range(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrows, const T* p_full, int64_t col0, int64_t col1, T* part,
+                           int64_t max_slots, int64_t* nslots) {
+    const int R = rows_per_thread(c);
+    const int64_t ncols = col1 - col0;
+    const int64_t bx = (nrows + 256 * R - 1) / (256 * R);
+    int64_t jsplit = c->kff_jsplit > 0 ? c->kff_jsplit : (8192 + bx - 1) / bx;
+    if (jsplit > max_slots) jsplit = max_slots;
+    if (jsplit > (ncols + 63) / 64) jsplit = (ncols + 63) / 64;
+    if (jsplit < 1) jsplit = 1;
+    int64_t jchunk = (ncols + jsplit - 1) / jsplit;
+    jchunk = (jchunk + 1) & ~(int64_t)1;
+    jsplit = (ncols + jchunk - 1) / jchunk;
+    *nslots = jsplit;
+    dim3 grid((unsigned)bx, (unsigned)jsplit);
+#define KFF_LAUNCH(RR)                                                                                               \
+    do {                                                                                                             \
+        if (c->exp_clamp)                                                                                            \
+            hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, true>), grid, dim3(256), 0, c->stream, XsRow,      \
+                               xaRow, nrows, (const T*)c->Xs, (const T*)c->xa, p_full, col0, col1, jchunk, part);    \
+        else                                                                                                         \
+            hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, false>), grid, dim3(256), 0, c->stream, XsRow,     \
+                               xaRow, nrows, (const T*)c->Xs, (const T*)c->xa, p_full, col0, col1, jchunk, part);    \
+    } while (0)
+    if (R == 4) { if constexpr (DP <= 8) KFF_LAUNCH(4); else if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
+    else if (R == 2) { if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
+    else KFF_LAUNCH(1);
+#undef KFF_LAUNCH
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
+template <typename T, int KIND, int DP>
+static int kff_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrows, const T* p_full, T* out, const T* pdiag,
+                       T noise, double* pdot_slot) {
+    if (nrows == 0) return CGLB_OK;
+    const size_t need = (size_t)512 * nrows * sizeof(T);
+    if (need > c->kpart_cap) {
+        if (c->kpart) HIP_CHECK(c, hipFree(c->kpart));
+        c->kpart = nullptr;
+        HIP_CHECK(c, hipMalloc(&c->kpart, need));
+        c->kpart_cap = need;
+    }
+    int64_t jsplit = 1;
+    CGLB_TRY((kff_pairs_range<T, KIND, DP>(c, XsRow, xaRow, nrows, p_full, 0, c->N, (T*)c->kpart, 512, &jsplit)));
+    return kff_combine<T>(c, jsplit, nrows, out, pdiag, noise, pdot_slot);
+}
+
+// plain pair kernel of the local row shard against columns [col0, col1) (used by the symmetric path for the
+// off-diagonal column ranges of a shard); at most 512 slots are written to `part`.
+int launch_kff_plain_range(cglb_ctx* c, const void* p_full, int64_t col0, int64_t col1, void* part, int64_t* nslots) {
+    CGLB_DISPATCH_ALL(c, return (kff_pairs_range<T, KIND, DP>(c, (const T*)c->Xs + c->r0 * DP, (const T*)c->xa + c->r0, c->nloc, (const T*)p_full,
+                                                              col0, col1, (T*)part, 512, nslots)));
+    return CGLB_OK;
+}
+
 // out_local = K_ff[rows,:] p + noise p[rows]; if pdot_slot != null also sum_i p_i out_i over local rows.
 int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot) {
+    if (c->nloc == 0) return CGLB_OK;
+    if (c->kff_variant == 2) return launch_kff_sym(c, p_full, out_local, pdot_slot);  // symmetric form (kernels_kff_sym.hip)
+    if (c->kff_variant == 1 && c->dtype == CGLB_F64 && (c->r0 & 15) == 0) {  // matrix-pipe Gram path (kernels_kff_mfma.hip)
+        int64_t jsplit = 1;
+        CGLB_TRY(launch_kff_mfma_pairs(c, (const double*)p_full, &jsplit));
+        return kff_combine<double>(c, jsplit, c->nloc, (double*)out_local, (const double*)p_full + c->r0, c->noise, pdot_slot);
+    }
     CGLB_DISPATCH_ALL(c, return (kff_generic<T, KIND, DP>(c, (const T*)c->Xs + c->r0 * DP, (const T*)c->xa + c->r0, c->nloc,
                                                           (const T*)p_full, (T*)out_local, (const T*)p_full + c->r0,
                                                           (T)c->noise, pdot_slot)));

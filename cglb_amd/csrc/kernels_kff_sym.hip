@@ -1,0 +1,254 @@
+// K1, symmetric form — the square block K[rows, rows] of the implicit mat-vec, each kernel value used twice.
+//
+// K_ff is symmetric, so for i < j one evaluation of kappa_ij serves out_i += kappa_ij p_j and out_j += kappa_ij p_i.
+// The pair evaluation (Gram chain + 2^x, ~22 vector-fp64 instructions) dominates, so halving the number of
+// evaluations is worth one extra fma per pair plus a cross-lane reduction:
+//   * a wave owns 64*R rows (R per lane, operands in VGPRs) and streams a chunk of columns j >= its first row;
+//     x_j / a_j / p_j are wave-uniform scalar loads exactly as in the plain kernel (kernels_kff.hip);
+//   * row sums stay in the lane that owns the row (no reduction);
+//   * the column contribution sum_i kappa_ij p_i of a column j is a sum ACROSS lanes.  Columns are taken in
+//     batches of 16; the 16 per-lane partials are reduced together by a transpose-reduce (4 select/shuffle/add
+//     stages that halve the number of live vectors, then two butterfly adds): ~3 fp64-instruction equivalents
+//     per column instead of 18 for sixteen separate wave reductions; the 16 sums land in lanes 0..15 and are
+//     stored with one 128-B store;
+//   * nothing is accumulated with atomics: every (slot, element) of the partial slabs is written by exactly one
+//     wave and the combine kernel adds the valid slots in fixed order, so results are bitwise reproducible.
+// Slab layout (element type double), n = number of rows of the square block:
+//   Prow[k][i], k < nchunk : row sums of chunk k (valid for k >= first chunk of row block rb(i))
+//   Pcol[rb][j], rb < nrb  : column sums produced by row block rb (valid for rb < rb(j))
+// The diagonal 64R x 64R blocks are evaluated in full and contribute row sums only.
+#include "devmath.h"
+#include "dispatch.h"
+
+#define SYM_BATCH 16
+
+template <typename T, int KIND, int DP, int R, bool CLAMP>
+__global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
+                                                      int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items, int nitems,
+                                                      T* __restrict__ Prow, T* __restrict__ Pcol) {
+    const int lane = threadIdx.x & 63;
+    // wave-uniform work item: readfirstlane makes that visible to the compiler, so everything derived from it
+    // (column indices, operand addresses) lives in SGPRs and the column operands are fetched with scalar loads
+    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (item >= nitems) return;  // whole wave exits together
+    const int2 it = items[item];
+    const int64_t rb = __builtin_amdgcn_readfirstlane(it.x), k = __builtin_amdgcn_readfirstlane(it.y);
+    constexpr int RBROWS = 64 * R;
+    const int64_t rbase = rb * RBROWS;
+    T xi[R][DP], ai[R], pr[R], acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = rbase + r * 64 + lane;
+        const int64_t rr = row < n ? row : n - 1;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xi[r][d] = Xs[(row0 + rr) * DP + d];
+        const T a = xa[row0 + rr];
+        ai[r] = (KIND == CGLB_RBF) ? a : T(-0.5) * a;
+        pr[r] = row < n ? p[row0 + rr] : T(0);
+        acc[r] = 0;
+    }
+    int64_t j0 = k * chunk;
+    if (j0 < rbase) j0 = rbase;
+    int64_t j1 = (k + 1) * chunk;
+    if (j1 > n) j1 = n;
+    const int64_t sym_from = rbase + RBROWS;  // columns at or beyond this get the transposed contribution
+    // j0 and chunk are multiples of 16, so only the very last batch of the block (j1 == n) can be short
+    const int64_t jfull = j0 + ((j1 - j0) / SYM_BATCH) * SYM_BATCH;
+    for (int64_t jb = j0; jb < jfull; jb += SYM_BATCH) {
+        const T* __restrict__ xsj = Xs + (row0 + jb) * DP;  // wave-uniform bases: the loads below are s_load with immediate offsets
+        const T* __restrict__ xaj = xa + row0 + jb;
+        const T* __restrict__ pjv = p + row0 + jb;
+        T t[SYM_BATCH];
+#pragma unroll
+        for (int jj = 0; jj < SYM_BATCH; ++jj) {
+            const T aj = xaj[jj];
+            const T pj = pjv[jj];
+            T xj[DP];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) xj[d] = xsj[jj * DP + d];
+            T tj = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                T gram = ai[r];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) gram = tfma<T>(xi[r][d], xj[d], gram);
+                const T kap = kappa_from_gram<T, KIND, CLAMP>(gram, aj);
+                acc[r] = tfma<T>(kap, pj, acc[r]);
+                tj = tfma<T>(kap, pr[r], tj);
+            }
+            t[jj] = tj;
+            // Pin the accumulators at the end of every column: without this the optimizer sinks the 2*R accumulate
+            // fmas of all 16 unrolled columns below the batch (64 kernel values kept live = 128 extra VGPRs), and the
+            // scheduler hoists the scalar operand loads of all 16 columns (320 SGPRs, spills).
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[r]));
+            asm volatile("" : "+v"(t[jj]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (jb >= sym_from) {  // wave-uniform
+            // transpose-reduce: after stage s the vector q holds, in lane l, the sum over the lanes that differ from l in
+            // bits 0..s, of column 2^(s+1) q + (l & (2^(s+1)-1)).
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool hi = (lane >> s) & 1;
+#pragma unroll
+                for (int q = 0; q < (SYM_BATCH >> (s + 1)); ++q) {
+                    const T a = t[2 * q], b = t[2 * q + 1];
+                    const T keep = hi ? b : a;
+                    const T send = hi ? a : b;
+                    t[q] = keep + __shfl_xor(send, 1 << s, 64);
+                }
+            }
+            T v = t[0];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < SYM_BATCH) Pcol[rb * n + jb + lane] = v;
+        }
+    }
+    // ragged tail of the block (fewer than 16 columns): one column at a time, plain wave reduction
+    for (int64_t jc = jfull; jc < j1; ++jc) {
+        const int64_t j = row0 + jc;
+        const T aj = xa[j];
+        const T pj = p[j];
+        T xj[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
+        T tj = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            T gram = ai[r];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) gram = tfma<T>(xi[r][d], xj[d], gram);
+            const T kap = kappa_from_gram<T, KIND, CLAMP>(gram, aj);
+            acc[r] = tfma<T>(kap, pj, acc[r]);
+            tj = tfma<T>(kap, pr[r], tj);
+        }
+        if (jc >= sym_from) {
+            const T v = wave_sum(tj);
+            if (lane == 0) Pcol[rb * n + jc] = v;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = rbase + r * 64 + lane;
+        if (row < n) Prow[k * n + row] = acc[r];
+    }
+}
+
+// out[i] = var * ( sum_s plain[s][i] + sum_{k >= k0(i)} Prow[k][i] + sum_{rb < rb(i)} Pcol[rb][i] ) + noise * pdiag[i]
+template <typename T>
+__global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restrict__ plain, int nplain, const T* __restrict__ Prow, int nchunk,
+                                                              const T* __restrict__ Pcol, int64_t n, int64_t chunk, int rbrows, T var, T noise,
+                                                              const T* __restrict__ pdiag, T* __restrict__ out, double* __restrict__ dotpart) {
+    __shared__ double smem[16];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double contrib = 0.0;
+    if (i < n) {
+        T s = 0;
+        for (int q = 0; q < nplain; ++q) s += plain[(int64_t)q * n + i];
+        const int64_t rbi = i / rbrows;
+        const int64_t k0 = (rbi * rbrows) / chunk;
+        for (int64_t k = k0; k < nchunk; ++k) s += Prow[k * n + i];
+        for (int64_t rb = 0; rb < rbi; ++rb) s += Pcol[rb * n + i];
+        T o = var * s;
+        o = tfma<T>(noise, pdiag[i], o);
+        contrib = (double)pdiag[i] * (double)o;
+        out[i] = o;
+    }
+    if (dotpart) {
+        const double bs = block_sum(contrib, smem);
+        if (threadIdx.x == 0) dotpart[blockIdx.x] = bs;
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_sum_sym_kernel(const double* __restrict__ partials, int n, double* __restrict__ out) {
+    __shared__ double smem[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += partials[i];
+    s = block_sum(s, smem);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+
+static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, int* nitems_out, int* nrb_out, int* nchunk_out) {
+    const int nrb = (int)((n + rbrows - 1) / rbrows);
+    const int nchunk = (int)((n + chunk - 1) / chunk);
+    if (c->sym_items && c->sym_n == n && c->sym_rbrows == rbrows && c->sym_chunk == chunk) {
+        *nitems_out = c->sym_nitems; *nrb_out = nrb; *nchunk_out = nchunk;
+        return CGLB_OK;
+    }
+    std::vector<int2> items;
+    // longest rows first (row block 0 sweeps the most columns): helps the tail of the launch
+    for (int rb = 0; rb < nrb; ++rb) {
+        const int k0 = (int)(((int64_t)rb * rbrows) / chunk);
+        for (int k = k0; k < nchunk; ++k) items.push_back(make_int2(rb, k));
+    }
+    if (c->sym_items) HIP_CHECK(c, hipFree(c->sym_items));
+    c->sym_items = nullptr;
+    HIP_CHECK(c, hipMalloc(&c->sym_items, items.size() * sizeof(int2)));
+    HIP_CHECK(c, hipMemcpyAsync(c->sym_items, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    c->sym_n = n; c->sym_rbrows = rbrows; c->sym_chunk = chunk; c->sym_nitems = (int)items.size();
+    *nitems_out = c->sym_nitems; *nrb_out = nrb; *nchunk_out = nchunk;
+    return CGLB_OK;
+}
+
+template <typename T, int KIND, int DP>
+static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* pdot_slot) {
+    constexpr int R = (DP <= 8) ? 4 : (DP <= 16 ? 2 : 1);
+    constexpr int RBROWS = 64 * R;
+    const int64_t n = c->nloc;
+    int64_t chunk = c->sym_chunk_opt > 0 ? c->sym_chunk_opt : 1024;
+    chunk = (chunk + SYM_BATCH - 1) / SYM_BATCH * SYM_BATCH;
+    int nitems = 0, nrb = 0, nchunk = 0;
+    CGLB_TRY(ensure_sym_items(c, n, RBROWS, chunk, &nitems, &nrb, &nchunk));
+    // off-diagonal column ranges of the row shard ([0,r0) and [r1,N)) go through the plain kernel
+    const int64_t nleft = c->r0, nright = c->N - c->r1;
+    int64_t plain_slots_max = 0;
+    if (nleft > 0 || nright > 0) plain_slots_max = 2 * 512;
+    const size_t need = ((size_t)plain_slots_max + nchunk + nrb) * n * sizeof(T);
+    if (need > c->kpart_cap) {
+        if (c->kpart) HIP_CHECK(c, hipFree(c->kpart));
+        c->kpart = nullptr;
+        HIP_CHECK(c, hipMalloc(&c->kpart, need));
+        c->kpart_cap = need;
+    }
+    T* plain = (T*)c->kpart;
+    int64_t nplain = 0;
+    if (nleft > 0) {
+        int64_t ns = 0;
+        CGLB_TRY(launch_kff_plain_range(c, p_full, 0, c->r0, plain, &ns));
+        nplain += ns;
+    }
+    if (nright > 0) {
+        int64_t ns = 0;
+        CGLB_TRY(launch_kff_plain_range(c, p_full, c->r1, c->N, plain + nplain * n, &ns));
+        nplain += ns;
+    }
+    T* Prow = plain + nplain * n;
+    T* Pcol = Prow + (int64_t)nchunk * n;
+    const int grid = (nitems + 3) / 4;
+    if (c->exp_clamp)
+        hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xs, (const T*)c->xa, p_full, c->r0,
+                           n, chunk, (const int2*)c->sym_items, nitems, Prow, Pcol);
+    else
+        hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xs, (const T*)c->xa, p_full, c->r0,
+                           n, chunk, (const int2*)c->sym_items, nitems, Prow, Pcol);
+    CGLB_LAUNCH_CHECK(c);
+    if (c->kff_skip_combine) return CGLB_OK;
+    const int cgrid = (int)((n + 255) / 256);
+    if (pdot_slot && cgrid > DOTPART_CAP) return cglb_fail(c, CGLB_ERR_BAD_ARG, "row shard too large for dot partials");
+    hipLaunchKernelGGL((kff_sym_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)plain, (int)nplain, (const T*)Prow, nchunk,
+                       (const T*)Pcol, n, chunk, RBROWS, (T)c->var, (T)c->noise, p_full + c->r0, out_local, pdot_slot ? c->dotpart : nullptr);
+    CGLB_LAUNCH_CHECK(c);
+    if (pdot_slot) {
+        hipLaunchKernelGGL(finalize_sum_sym_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, cgrid, pdot_slot);
+        CGLB_LAUNCH_CHECK(c);
+    }
+    return CGLB_OK;
+}
+
+int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot) {
+    CGLB_DISPATCH_ALL(c, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out_local, pdot_slot)));
+    return CGLB_OK;
+}

@@ -1,0 +1,65 @@
+"""All K_ff mat-vec kernel variants against the dense oracle / the blocked C oracle, including ragged sizes
+(N not a multiple of 16/64/256), D in {1,3,8,16}, both kernels."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cglb_oracle as orc
+from oracle import cglb_oracle_c as orcc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+@pytest.mark.parametrize("N,D", [(257, 1), (1000, 3), (4099, 8), (2500, 16), (333, 5)])
+def test_matvec_variants(variant, kind, N, D):
+    from cglb_amd.hip_context import HipContext
+    X, y, Z = orc.synthetic_problem(N, D, 8, seed=N + D)
+    rng = np.random.default_rng(1)
+    hyp = orc.Hypers(0.6 + rng.random(D), 0.7, 0.3, 0.1, Z, 1e-6)
+    ctx = HipContext(X, y, 8, kind)
+    ctx.set_option("kff_variant", variant)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, 1e-6)
+    p = rng.standard_normal(N)
+    out = ctx.matvec(torch.from_numpy(p)).cpu().numpy()
+    ref = orcc.kff_matvec(kind, X, hyp, p)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-12 * np.abs(ref).max())
+    # duplicated points (distance exactly 0) and a far outlier (kernel underflow)
+    X2 = X.copy()
+    X2[1] = X2[0]
+    X2[2] = 50.0
+    ctx2 = HipContext(X2, y, 8, kind)
+    ctx2.set_option("kff_variant", variant)
+    ctx2.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, 1e-6)
+    out2 = ctx2.matvec(torch.from_numpy(p)).cpu().numpy()
+    ref2 = orcc.kff_matvec(kind, X2, hyp, p)
+    np.testing.assert_allclose(out2, ref2, rtol=0, atol=5e-10 * np.abs(ref2).max())  # Gram form with a far outlier: |x|^2 eps
+    assert np.isfinite(out2).all()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_matvec_row_shard_and_linearity(variant):
+    from cglb_amd.hip_context import HipContext
+    N, D = 3000, 8
+    X, y, Z = orc.synthetic_problem(N, D, 8, seed=3)
+    h = orc.trained_like_hypers(D, Z)
+    rng = np.random.default_rng(2)
+    p, q = rng.standard_normal(N), rng.standard_normal(N)
+    full = HipContext(X, y, 8, "rbf")
+    full.set_option("kff_variant", variant)
+    full.set_hypers(h.lengthscales, h.variance, h.noise, h.mean, Z, 1e-6)
+    ref = full.matvec(torch.from_numpy(p)).cpu().numpy()
+    for r0, r1 in [(0, 1504), (1504, 3000), (1600, 1601)]:
+        sh = HipContext(X, y, 8, "rbf", row_range=(r0, r1))
+        sh.set_option("kff_variant", variant)
+        sh.set_hypers(h.lengthscales, h.variance, h.noise, h.mean, Z, 1e-6)
+        np.testing.assert_allclose(sh.matvec(torch.from_numpy(p)).cpu().numpy(), ref[r0:r1], rtol=0, atol=1e-12 * np.abs(ref).max())
+    # linearity and symmetry: q^T (A p) == p^T (A q)
+    Aq = full.matvec(torch.from_numpy(q)).cpu().numpy()
+    Apq = full.matvec(torch.from_numpy(2.0 * p - 0.5 * q)).cpu().numpy()
+    np.testing.assert_allclose(Apq, 2.0 * ref - 0.5 * Aq, rtol=0, atol=1e-11 * np.abs(ref).max())
+    assert q @ ref == pytest.approx(p @ Aq, rel=1e-11)
+    # run-twice determinism (fixed-order combine, no atomics)
+    again = full.matvec(torch.from_numpy(p)).cpu().numpy()
+    assert np.array_equal(again, ref)
