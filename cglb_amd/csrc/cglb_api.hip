@@ -255,8 +255,17 @@ int require_single(cglb_ctx* c) {
 int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter, int restart_iter, int* steps, double* half_rz) {
     double* S = c->scal;
     // :57-61  Av = A v ; r = b - Av ; z, rz = P(r) ; p = z
-    CGLB_TRY(launch_kff_matvec(c, v, c->w_Kv, nullptr));
-    CGLB_TRY(launch_residual(c, c->w_r, b, c->w_Kv));
+    // A cold start (v == 0, models.py:59-68) gives Av == 0 and r == b exactly, so the mat-vec is skipped in that case;
+    // the result is bit-identical to computing it.
+    double vnorm = 0.0;
+    CGLB_TRY(launch_dot(c, v, v, c->nloc, S + S_TMP));
+    CGLB_TRY(read_scalars(c, S + S_TMP, &vnorm, 1));
+    if (vnorm == 0.0) {
+        HIP_CHECK(c, hipMemcpyAsync(c->w_r, b, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        CGLB_TRY(launch_kff_matvec(c, v, c->w_Kv, nullptr));
+        CGLB_TRY(launch_residual(c, c->w_r, b, c->w_Kv));
+    }
     CGLB_TRY(precond_single(c, c->w_r, c->w_z, S + S_RZ));
     HIP_CHECK(c, hipMemcpyAsync(c->w_p, c->w_z, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
     double rz = 0;

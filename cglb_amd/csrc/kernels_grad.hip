@@ -12,15 +12,21 @@
 #include "dispatch.h"
 
 // ---- N^2 pass ---------------------------------------------------------------------------------------
-// Thread owns R rows; column operand (xs_j, v_j) is wave-uniform (scalar loads).
-// part[(by * gridDim.x + bx) * DP + d] = sum_{i in block} u_i sum_{j in chunk} h_ij v_j (xs_id - xs_jd)^2
-template <typename T, int KIND, int DP, int R>
-__global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsRow, const T* __restrict__ u_local, int64_t nrows,
-                                                       const T* __restrict__ Xs, const T* __restrict__ v, int64_t N, int64_t jchunk,
+// Thread owns R rows; the column operand (xs_j, v_j, u_j) is wave-uniform (scalar loads).
+// part[(blk0 + by * gridDim.x + bx) * DP + d] = sum over the block's pairs of w_ij h_ij (xs_id - xs_jd)^2
+//   SYM = false: rows x columns [0, ncols) of another index range, w_ij = u_i v_j.
+//   SYM = true : the square block rows x rows.  The form is symmetric under i <-> j, so only columns at or beyond the
+//                block's first row are visited: the diagonal 256R x 256R block in full with w = u_i v_j, everything to its
+//                right once with w = u_i v_j + u_j v_i  (halves the pair evaluations).
+template <typename T, int KIND, int DP, int R, bool SYM>
+__global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsRow, const T* __restrict__ uRow, const T* __restrict__ vRow,
+                                                       int64_t nrows, const T* __restrict__ XsCol, const T* __restrict__ vCol,
+                                                       const T* __restrict__ uCol, int64_t ncols, int64_t jchunk, int64_t blk0,
                                                        double* __restrict__ part) {
     __shared__ double smem[16];
-    const int64_t rbase = (int64_t)blockIdx.x * (256 * R) + threadIdx.x;
-    T xi[R][DP], acc[R][DP], ui[R];
+    const int64_t rblock = (int64_t)blockIdx.x * (256 * R);
+    const int64_t rbase = rblock + threadIdx.x;
+    T xi[R][DP], acc[R][DP], ui[R], vi[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int64_t row = rbase + (int64_t)k * 256;
@@ -30,15 +36,20 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
             xi[k][d] = XsRow[rr * DP + d];
             acc[k][d] = 0;
         }
-        ui[k] = row < nrows ? u_local[rr] : T(0);
+        ui[k] = row < nrows ? uRow[rr] : T(0);
+        vi[k] = (SYM && row < nrows) ? vRow[rr] : T(0);
     }
-    const int64_t j0 = (int64_t)blockIdx.y * jchunk;
-    const int64_t j1 = (j0 + jchunk < N) ? j0 + jchunk : N;
+    int64_t j0 = (int64_t)blockIdx.y * jchunk;
+    const int64_t j1 = (j0 + jchunk < ncols) ? j0 + jchunk : ncols;
+    const int64_t sym_from = rblock + 256 * R;
+    if (SYM && j0 < rblock) j0 = rblock;
     for (int64_t j = j0; j < j1; ++j) {
-        const T vj = v[j];
+        const T vj = vCol[j];
+        T wu = 0;
+        if (SYM) wu = (j >= sym_from) ? uCol[j] : T(0);  // wave-uniform
         T xj[DP];
 #pragma unroll
-        for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
+        for (int d = 0; d < DP; ++d) xj[d] = XsCol[j * DP + d];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             T sq[DP];
@@ -49,7 +60,9 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
                 sq[d] = df * df;
                 d2 += sq[d];
             }
-            const T hv = hfac_from_d2<T, KIND>(d2) * vj;
+            T w = ui[k] * vj;
+            if (SYM) w = tfma<T>(vi[k], wu, w);
+            const T hv = hfac_from_d2<T, KIND>(d2) * w;
 #pragma unroll
             for (int d = 0; d < DP; ++d) acc[k][d] = tfma<T>(hv, sq[d], acc[k][d]);
         }
@@ -58,9 +71,9 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
     for (int d = 0; d < DP; ++d) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) s += (double)ui[k] * (double)acc[k][d];
+        for (int k = 0; k < R; ++k) s += (double)acc[k][d];
         s = block_sum(s, smem);
-        if (threadIdx.x == 0) part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * DP + d] = s;
+        if (threadIdx.x == 0) part[(blk0 + (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * DP + d] = s;
     }
 }
 
@@ -105,21 +118,36 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
     }
     const int R = c->Dp <= 8 ? 2 : 1;
     const int64_t bx = (c->nloc + 256 * R - 1) / (256 * R);
-    int64_t jsplit = (8192 + bx - 1) / bx;
-    if (jsplit > 512) jsplit = 512;
-    if (jsplit > (c->N + 63) / 64) jsplit = (c->N + 63) / 64;
-    if (jsplit < 1) jsplit = 1;
-    const int64_t jchunk = (c->N + jsplit - 1) / jsplit;
-    jsplit = (c->N + jchunk - 1) / jchunk;
-    const int64_t nblk = bx * jsplit;
+    // three column ranges: the square block (symmetric form) and the shard's off-diagonal ranges [0,r0), [r1,N)
+    struct Range { int64_t col0, ncols; bool sym; int64_t jsplit, jchunk; } rg[3] = {
+        {c->r0, c->nloc, true, 0, 0}, {0, c->r0, false, 0, 0}, {c->r1, c->N - c->r1, false, 0, 0}};
+    int64_t nblk = 0;
+    for (auto& r : rg) {
+        if (r.ncols <= 0) continue;
+        int64_t js = (8192 + bx - 1) / bx;
+        if (r.sym) js *= 2;  // about half of the (row block, chunk) cells of the square are left of the diagonal and exit at once
+        if (js > 1024) js = 1024;
+        if (js > (r.ncols + 63) / 64) js = (r.ncols + 63) / 64;
+        if (js < 1) js = 1;
+        r.jchunk = (r.ncols + js - 1) / js;
+        r.jsplit = (r.ncols + r.jchunk - 1) / r.jchunk;
+        nblk += bx * r.jsplit;
+    }
     CGLB_TRY(ensure_gpart(c, (size_t)nblk * c->Dp * sizeof(double)));
-    dim3 grid((unsigned)bx, (unsigned)jsplit);
-#define GK_LAUNCH(RR)                                                                                                      \
-    hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR>), grid, dim3(256), 0, c->stream, (const T*)c->Xs + c->r0 * DP,      \
-                       (const T*)u_local, c->nloc, (const T*)c->Xs, (const T*)v_full, c->N, jchunk, c->gpart)
-    CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2); } else { GK_LAUNCH(1); });
+    int64_t blk0 = 0;
+    for (auto& r : rg) {
+        if (r.ncols <= 0) continue;
+        dim3 grid((unsigned)bx, (unsigned)r.jsplit);
+#define GK_LAUNCH(RR, SYMV)                                                                                                        \
+    hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, SYMV>), grid, dim3(256), 0, c->stream, (const T*)c->Xs + c->r0 * DP,        \
+                       (const T*)u_local, (const T*)v_full + c->r0, c->nloc, (const T*)c->Xs + r.col0 * DP, (const T*)v_full + r.col0, \
+                       (const T*)u_local, r.ncols, r.jchunk, blk0, c->gpart)
+        if (r.sym) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); }); }
+        else { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); }); }
 #undef GK_LAUNCH
-    CGLB_LAUNCH_CHECK(c);
+        CGLB_LAUNCH_CHECK(c);
+        blk0 += bx * r.jsplit;
+    }
     hipLaunchKernelGGL(grad_dl_finalize_kernel, dim3(c->D), dim3(256), 0, c->stream, (const double*)c->gpart, nblk, c->Dp, c->D, sp,
                        c->var, out_dl, 0);
     CGLB_LAUNCH_CHECK(c);
