@@ -178,15 +178,26 @@ def main():
     achieved = flops / (ms_pair * 1e-3) / 1e12
     esz = 8
     prec_bytes = 2.0 * M * nloc * esz + 3.0 * nloc * esz
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE);
+    # only quoted for the workload it was collected on (single GPU, headline size)
+    traffic_k1 = traffic_prec = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    if world == 1 and (N, D, M, kind) == (100_000, 8, 1024, "rbf") and os.path.exists(pmc_file):
+        pk = json.load(open(pmc_file))["kernels"]
+        traffic_k1 = pk["kff_sym_kernel"]["hbm_bytes_per_launch"]
+        traffic_prec = sum(pk[k]["hbm_bytes_per_launch"] for k in ("gemv_u_kernel", "gemv_t_kernel", "precond_z_kernel"))
     roofline = {
-        "kernel": "kff_matvec_kernel", "bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms_pair,
-        "algorithmic": f"{pair_flops(kind, D)} flop/pair x N x n_local pairs per launch (K_ff never materialised; HBM bytes N(D+2)w are negligible)",
+        "kernel": "kff_sym_kernel (pair kernel of the implicit K_ff mat-vec)", "bound": "valu_fp64", "achieved": achieved,
+        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_k1,
+        "ms_per_launch": ms_pair,
+        "algorithmic": (f"{pair_flops(kind, D)} flop/pair x N x n_local pairs per launch; K_ff is never materialised, algorithmic HBM bytes "
+                        f"N(D+2)w = {N * (D + 2) * 8 / 1e6:.1f} MB; the symmetric kernel evaluates each pair of the square block once"),
     }
     roofline_hbm = {
-        "kernel": "nystrom preconditioner apply (gemv_u_kernel + gemv_t_kernel over the stored panel A)", "bound": "hbm",
+        "kernel": "nystrom preconditioner apply (gemv_u_kernel + gemv_t_kernel over the stored panel A + precond_z_kernel)", "bound": "hbm",
         "achieved": prec_bytes / (ms_prec * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": prec_bytes / (ms_prec * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms_per_apply": ms_prec,
+        "frac": prec_bytes / (ms_prec * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_prec, "ms_per_apply": ms_prec,
+        "algorithmic": "2 M n_local w + 3 n_local w bytes per apply",
     }
 
     cpu = None
