@@ -413,6 +413,13 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     const size_t e = c->esz, N = (size_t)c->N, nl = (size_t)c->nloc, M = (size_t)m, Dp = (size_t)c->Dp;
     CR(dalloc(c, &c->X, N * d * e)); CR(dalloc(c, &c->y, N * e)); CR(dalloc(c, &c->Z, M * d * e));
     CR(dalloc(c, &c->Xs, N * Dp * e)); CR(dalloc(c, &c->xa, N * e)); CR(dalloc(c, &c->Zs, M * Dp * e)); CR(dalloc(c, &c->za, M * e));
+    CR(dalloc(c, &c->Xh, N * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, (void**)&c->exp_tab, 64 * sizeof(double)));
+    {
+        double tab[64];
+        for (int k = 0; k < 64; ++k) tab[k] = std::exp2((double)k / 64.0);  // glibc exp2 is correctly rounded to < 1 ulp
+        hipError_t e3 = hipMemcpy(c->exp_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
+        if (e3 != hipSuccess) { c->err = "exp table upload failed"; return fail(CGLB_ERR_HIP); }
+    }
     CR(dalloc(c, &c->At, M * (size_t)c->lda * e));
     CR(dalloc(c, &c->Lc, M * M * e)); CR(dalloc(c, &c->LBc, M * M * e)); CR(dalloc(c, &c->LBinv, M * M * e)); CR(dalloc(c, &c->LBinvT, M * M * e));
     CR(dalloc(c, &c->AAt, M * M * e)); CR(dalloc(c, &c->Mtmp, M * M * e)); CR(dalloc(c, &c->Mtmp2, M * M * e));
@@ -434,7 +441,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     if (!c) return CGLB_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
+    void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->xah, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
                     c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -494,9 +501,10 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
         const double ks = (c->kind == CGLB_RBF) ? std::sqrt(CGLB_LOG2E) : CGLB_SQRT3 * CGLB_LOG2E;
         double s2 = 0.0;
         for (int d = 0; d < c->D; ++d) { const double v = c->xrange[d] * ks / c->ls[d]; s2 += v * v; }
-        c->exp_clamp = !(2.0 * s2 < 1.0e9);
+        c->exp_clamp = !(2.0 * s2 * CGLB_HOT_UNITS * (c->kind == CGLB_RBF ? 1.0 : CGLB_HOT_UNITS) < 1.0e9);
     }
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
+    CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xh, c->xah, true));
     CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zs, c->za));
     CGLB_TRY(launch_frag_prep(c));
     c->have_local = c->have_terms = false;
@@ -561,7 +569,7 @@ int cglb_cross_matvec(cglb_ctx* c, const void* xnew, int64_t n_new, const void* 
     int rc = CGLB_OK;
     hipError_t e = hipMemcpyAsync(xr, xnew, (size_t)n_new * c->D * c->esz, hipMemcpyDefault, c->stream);
     if (e != hipSuccess) rc = cglb_fail(c, CGLB_ERR_HIP, "copy of xnew failed");
-    if (rc == CGLB_OK) rc = launch_prep_scaled(c, xr, n_new, xs, xa);
+    if (rc == CGLB_OK) rc = launch_prep_scaled(c, xr, n_new, xs, xa, true);  // rows of the pair kernel: hot units
     if (rc == CGLB_OK) rc = launch_cross_matvec(c, xs, xa, n_new, v_full, out);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(xr); (void)hipFree(xs); (void)hipFree(xa);
@@ -685,8 +693,9 @@ int cglb_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_ne
     HIP_CHECK(c, hipMalloc(&t2, (size_t)M * ld * c->esz));
     auto body = [&]() -> int {
         HIP_CHECK(c, hipMemcpyAsync(xr, xnew, (size_t)n_new * c->D * c->esz, hipMemcpyDefault, c->stream));
-        CGLB_TRY(launch_prep_scaled(c, xr, n_new, xs, xa));
+        CGLB_TRY(launch_prep_scaled(c, xr, n_new, xs, xa, true));               // hot units for the pair kernel
         CGLB_TRY(launch_cross_matvec(c, xs, xa, n_new, v_full, f_mean));       // cg_mean = ksf @ v   (models.py:334)
+        CGLB_TRY(launch_prep_scaled(c, xr, n_new, xs, xa, false));             // plain scaled units for the K_us panel
         CGLB_TRY(launch_sub_scalar(c, c->w_e, c->y, c->mean, c->nloc));        // err                  (:318)
         CGLB_TRY(launch_kff_matvec(c, v_full, c->w_Kv, nullptr));
         CGLB_TRY(launch_residual(c, c->w_r, c->w_e, c->w_Kv));                 // res = err - cov @ v  (:335)

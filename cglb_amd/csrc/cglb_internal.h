@@ -32,6 +32,8 @@ struct cglb_ctx {
     double var = 1, noise = 1, mean = 0, jitter = 1e-6;
     // scaled operands of the streaming kernels (T): xs = (x-c)/l*kscale padded to Dp, xa = per-row norm term
     void *Xs = nullptr, *xa = nullptr, *Zs = nullptr, *za = nullptr;
+    void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/64 octave (devmath.h exp2_tab)
+    double* exp_tab = nullptr;           // device table 2^(k/64), k < 64
     // common terms (column-major M x M unless noted)
     void* At = nullptr;      // A as [M][nloc] row-major == (nloc x M) column-major, ld = nloc
     void* Lc = nullptr;      // chol(Kuu + jitter I), lower, column-major
@@ -110,7 +112,8 @@ static inline int pad_dim(int d) {
 
 // ---- launchers implemented in the kernel translation units (all enqueue on ctx->stream) ----------
 // kernels_prep.hip
-int launch_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out);
+int launch_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out, bool hot = false);
+double cglb_hot_scale(const cglb_ctx* c);  // xh = hot_scale * xs
 int launch_kuf(cglb_ctx* c);  // At <- Kuf[:, rows] (unscaled by sigma)
 int launch_kuu(cglb_ctx* c);  // Lc <- Kuu + jitter I (full symmetric)
 // kernels_kff.hip

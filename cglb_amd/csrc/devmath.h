@@ -74,6 +74,31 @@ __device__ __forceinline__ double sqrt_pos(double x) {
 }
 __device__ __forceinline__ float sqrt_pos(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
 
+// Table-driven 2^(x/64): the hot pair kernels keep their operands in units of 1/64 octave (x64 = 64*log2 of the value), so
+//   x64 = n + s, |s| <= 1/2;  2^(x64/64) = 2^(n>>6) * TAB[n & 63] * P5(s),  TAB[k] = 2^(k/64) (correctly rounded, in LDS),
+//   P5 = degree-5 polynomial for 2^(s/64) (1.1e-16).  Total error <= ~3e-16 (1.5 ulp).
+// 10 vector-fp64 instructions (rndne, add, 5 fma, cvt, mul, ldexp) + 3 cheap 32-bit integer ops + one ds_read_b64, against
+// 14 for the pure polynomial form: fp64 has no hardware transcendental on CDNA, and the pair kernels are bound by
+// vector-fp64 issue, so every instruction here is ~4 % of the mat-vec.
+#define CGLB_HOT_UNITS 64.0
+template <bool CLAMP> __device__ __forceinline__ double exp2_tab(double x64, const double* __restrict__ tab_lds) {
+    if (CLAMP) x64 = fmax(x64, -70400.0);
+    const double n = __builtin_rint(x64);
+    const double s = x64 - n;
+    const int ni = (int)n;
+    const double t = tab_lds[ni & 63];
+    double p = 0x1.5d8855325a3d0p-40;
+    p = __builtin_fma(p, s, 0x1.3b2ad54ddd7adp-31);
+    p = __builtin_fma(p, s, 0x1.c6b08d7044d9dp-23);
+    p = __builtin_fma(p, s, 0x1.ebfbdff829821p-15);
+    p = __builtin_fma(p, s, 0x1.62e42fefa39efp-7);
+    p = __builtin_fma(p, s, 1.0);
+    return __builtin_ldexp(t * p, ni >> 6);
+}
+template <bool CLAMP> __device__ __forceinline__ float exp2_tab(float x64, const double* __restrict__) {
+    return __builtin_amdgcn_exp2f(x64 * (1.0f / 64.0f));
+}
+
 template <typename T> __device__ __forceinline__ T tfma(T a, T b, T c);
 template <> __device__ __forceinline__ double tfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <> __device__ __forceinline__ float tfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -96,6 +121,71 @@ template <typename T, int KIND, bool CLAMP> __device__ __forceinline__ T kappa_f
         T r = sqrt_pos(tmax<T>(d2, T(0)));
         return tfma<T>(r, T(CGLB_LN2), T(1)) * exp2_hot<CLAMP>(-r);
     }
+}
+
+// Hot-unit forms (operands scaled so that exponents are in 1/64 octave, see exp2_tab):
+//   RBF:      xh = 8 xs, ah = 64 a          kappa = 2^((ah_i + ah_j + xh_i.xh_j)/64)
+//   Matern32: xh = 64 xs, ah = 4096 a       r64 = sqrt(max(ah_i + ah_j - 2 xh_i.xh_j, 0)),  kappa = (1 + r64 ln2/64) 2^(-r64/64)
+template <typename T, int KIND, bool CLAMP>
+__device__ __forceinline__ T kappa_hot_from_gram(T gram, T aj, const double* __restrict__ tab) {
+    if (KIND == CGLB_RBF) {
+        return exp2_tab<CLAMP>(gram + aj, tab);
+    } else {
+        T d2 = tfma<T>(T(-2), gram, aj);
+        T r = sqrt_pos(tmax<T>(d2, T(0)));
+        return tfma<T>(r, T(CGLB_LN2 / CGLB_HOT_UNITS), T(1)) * exp2_tab<CLAMP>(-r, tab);
+    }
+}
+// Two-phase form of kappa_hot_from_gram for software-pipelined loops: `begin` does the range reduction and issues the
+// table read, `end` consumes it, so that a loop can start the R lookups of a column before any of them is needed.
+template <typename T> struct KappaPend { T s; T lin; int ni; T tabv; };
+template <typename T, int KIND, bool CLAMP>
+__device__ __forceinline__ KappaPend<T> kappa_hot_begin(T gram, T aj, const double* __restrict__ tab) {
+    KappaPend<T> k;
+    T x64;
+    if (KIND == CGLB_RBF) {
+        x64 = gram + aj;
+        k.lin = T(1);
+    } else {
+        const T d2 = tfma<T>(T(-2), gram, aj);
+        const T r = sqrt_pos(tmax<T>(d2, T(0)));
+        k.lin = tfma<T>(r, T(CGLB_LN2 / CGLB_HOT_UNITS), T(1));
+        x64 = -r;
+    }
+    if (CLAMP) x64 = tmax<T>(x64, T(-70400.0));
+    const T n = __builtin_rint(x64);
+    k.s = x64 - n;
+    k.ni = (int)n;
+    k.tabv = (T)tab[k.ni & 63];
+    return k;
+}
+// polynomial part (independent of the table read): overwrites k.s with P5(s) [* lin for Matern]
+template <typename T, int KIND> __device__ __forceinline__ void kappa_hot_poly(KappaPend<T>& k) {
+    T p = T(0x1.5d8855325a3d0p-40);
+    p = tfma<T>(p, k.s, T(0x1.3b2ad54ddd7adp-31));
+    p = tfma<T>(p, k.s, T(0x1.c6b08d7044d9dp-23));
+    p = tfma<T>(p, k.s, T(0x1.ebfbdff829821p-15));
+    p = tfma<T>(p, k.s, T(0x1.62e42fefa39efp-7));
+    p = tfma<T>(p, k.s, T(1));
+    if (KIND != CGLB_RBF) p *= k.lin;
+    k.s = p;
+}
+template <typename T, int KIND> __device__ __forceinline__ T kappa_hot_end(const KappaPend<T>& k) {
+    return __builtin_ldexp(k.tabv * k.s, k.ni >> 6);
+}
+
+// gradient factor from an exact squared distance in hot units (RBF: d2h = 64 d2s; Matern32: d2h = 4096 d2s)
+template <typename T, int KIND, bool CLAMP> __device__ __forceinline__ T hfac_hot_from_d2(T d2h, const double* __restrict__ tab) {
+    if (KIND == CGLB_RBF) {
+        return exp2_tab<CLAMP>(T(-0.5) * d2h, tab);
+    } else {
+        return T(3) * exp2_tab<CLAMP>(-sqrt_pos(d2h), tab);
+    }
+}
+// cooperative load of the 64-entry table into LDS (call from every thread of the block, before any early exit)
+__device__ __forceinline__ void load_exp_table(double* tab_lds, const double* __restrict__ tab_global) {
+    if (threadIdx.x < 64) tab_lds[threadIdx.x] = tab_global[threadIdx.x];
+    __syncthreads();
 }
 
 // Kernel profile from an exact scaled squared distance (direct differences; used off the N^2 path).

@@ -22,8 +22,10 @@ template <typename T, int KIND, int DP, int R, bool SYM>
 __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsRow, const T* __restrict__ uRow, const T* __restrict__ vRow,
                                                        int64_t nrows, const T* __restrict__ XsCol, const T* __restrict__ vCol,
                                                        const T* __restrict__ uCol, int64_t ncols, int64_t jchunk, int64_t blk0,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, const double* __restrict__ exp_tab) {
     __shared__ double smem[16];
+    __shared__ double tab[64];
+    load_exp_table(tab, exp_tab);
     const int64_t rblock = (int64_t)blockIdx.x * (256 * R);
     const int64_t rbase = rblock + threadIdx.x;
     T xi[R][DP], acc[R][DP], ui[R], vi[R];
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
             }
             T w = ui[k] * vj;
             if (SYM) w = tfma<T>(vi[k], wu, w);
-            const T hv = hfac_from_d2<T, KIND>(d2) * w;
+            const T hv = hfac_hot_from_d2<T, KIND, true>(d2, tab) * w;
 #pragma unroll
             for (int d = 0; d < DP; ++d) acc[k][d] = tfma<T>(hv, sq[d], acc[k][d]);
         }
@@ -107,7 +109,7 @@ static inline double kscale_of(const cglb_ctx* c) { return (c->kind == CGLB_RBF)
 // out_dl[d] (device double[D], overwritten) = sum_{i local, j} u_i dK_ij/dl_d v_j
 int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double* out_dl) {
     ScaleParams sp;
-    const double ks = kscale_of(c);
+    const double ks = kscale_of(c) * cglb_hot_scale(c);  // the N^2 pass runs on the hot operand set
     for (int d = 0; d < CGLB_MAX_D; ++d) {
         sp.center[d] = 0;
         sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
@@ -139,9 +141,9 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
         if (r.ncols <= 0) continue;
         dim3 grid((unsigned)bx, (unsigned)r.jsplit);
 #define GK_LAUNCH(RR, SYMV)                                                                                                        \
-    hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, SYMV>), grid, dim3(256), 0, c->stream, (const T*)c->Xs + c->r0 * DP,        \
-                       (const T*)u_local, (const T*)v_full + c->r0, c->nloc, (const T*)c->Xs + r.col0 * DP, (const T*)v_full + r.col0, \
-                       (const T*)u_local, r.ncols, r.jchunk, blk0, c->gpart)
+    hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, SYMV>), grid, dim3(256), 0, c->stream, (const T*)c->Xh + c->r0 * DP,        \
+                       (const T*)u_local, (const T*)v_full + c->r0, c->nloc, (const T*)c->Xh + r.col0 * DP, (const T*)v_full + r.col0, \
+                       (const T*)u_local, r.ncols, r.jchunk, blk0, c->gpart, (const double*)c->exp_tab)
         if (r.sym) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); }); }
         else { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); }); }
 #undef GK_LAUNCH

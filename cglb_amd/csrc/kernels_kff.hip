@@ -18,7 +18,10 @@ template <typename T, int KIND, int DP, int R, bool CLAMP>
 __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ XsRow, const T* __restrict__ xaRow,
                                                          int64_t nrows, const T* __restrict__ Xs,
                                                          const T* __restrict__ xa, const T* __restrict__ p, int64_t col0,
-                                                         int64_t col1, int64_t jchunk, T* __restrict__ part) {
+                                                         int64_t col1, int64_t jchunk, T* __restrict__ part,
+                                                         const double* __restrict__ exp_tab) {
+    __shared__ double tab[64];
+    load_exp_table(tab, exp_tab);
     const int64_t rbase = (int64_t)blockIdx.x * (256 * R) + threadIdx.x;
     T xi[R][DP], ai[R], acc[R];
 #pragma unroll
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ X
             T gram = ai[k];
 #pragma unroll
             for (int d = 0; d < DP; ++d) gram = tfma<T>(xi[k][d], xj[d], gram);
-            const T kap = kappa_from_gram<T, KIND, CLAMP>(gram, aj);
+            const T kap = kappa_hot_from_gram<T, KIND, CLAMP>(gram, aj, tab);
             acc[k] = tfma<T>(kap, pj, acc[k]);
         }
     }
@@ -131,10 +134,12 @@ static int kff_pairs_range(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t 
     do {                                                                                                             \
         if (c->exp_clamp)                                                                                            \
             hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, true>), grid, dim3(256), 0, c->stream, XsRow,      \
-                               xaRow, nrows, (const T*)c->Xs, (const T*)c->xa, p_full, col0, col1, jchunk, part);    \
+                               xaRow, nrows, (const T*)c->Xh, (const T*)c->xah, p_full, col0, col1, jchunk, part, \
+                               (const double*)c->exp_tab);                                                          \
         else                                                                                                         \
             hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, false>), grid, dim3(256), 0, c->stream, XsRow,     \
-                               xaRow, nrows, (const T*)c->Xs, (const T*)c->xa, p_full, col0, col1, jchunk, part);    \
+                               xaRow, nrows, (const T*)c->Xh, (const T*)c->xah, p_full, col0, col1, jchunk, part, \
+                               (const double*)c->exp_tab);                                                          \
     } while (0)
     if (R == 4) { if constexpr (DP <= 8) KFF_LAUNCH(4); else if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
     else if (R == 2) { if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
@@ -163,7 +168,7 @@ static int kff_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrow
 // plain pair kernel of the local row shard against columns [col0, col1) (used by the symmetric path for the
 // off-diagonal column ranges of a shard); at most 512 slots are written to `part`.
 int launch_kff_plain_range(cglb_ctx* c, const void* p_full, int64_t col0, int64_t col1, void* part, int64_t* nslots) {
-    CGLB_DISPATCH_ALL(c, return (kff_pairs_range<T, KIND, DP>(c, (const T*)c->Xs + c->r0 * DP, (const T*)c->xa + c->r0, c->nloc, (const T*)p_full,
+    CGLB_DISPATCH_ALL(c, return (kff_pairs_range<T, KIND, DP>(c, (const T*)c->Xh + c->r0 * DP, (const T*)c->xah + c->r0, c->nloc, (const T*)p_full,
                                                               col0, col1, (T*)part, 512, nslots)));
     return CGLB_OK;
 }
@@ -177,7 +182,7 @@ int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* 
         CGLB_TRY(launch_kff_mfma_pairs(c, (const double*)p_full, &jsplit));
         return kff_combine<double>(c, jsplit, c->nloc, (double*)out_local, (const double*)p_full + c->r0, c->noise, pdot_slot);
     }
-    CGLB_DISPATCH_ALL(c, return (kff_generic<T, KIND, DP>(c, (const T*)c->Xs + c->r0 * DP, (const T*)c->xa + c->r0, c->nloc,
+    CGLB_DISPATCH_ALL(c, return (kff_generic<T, KIND, DP>(c, (const T*)c->Xh + c->r0 * DP, (const T*)c->xah + c->r0, c->nloc,
                                                           (const T*)p_full, (T*)out_local, (const T*)p_full + c->r0,
                                                           (T)c->noise, pdot_slot)));
     return CGLB_OK;

@@ -25,7 +25,9 @@
 template <typename T, int KIND, int DP, int R, bool CLAMP>
 __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items, int nitems,
-                                                      T* __restrict__ Prow, T* __restrict__ Pcol) {
+                                                      T* __restrict__ Prow, T* __restrict__ Pcol, const double* __restrict__ exp_tab) {
+    __shared__ double tab[64];
+    load_exp_table(tab, exp_tab);  // before the early exit below: every thread reaches the barrier inside
     const int lane = threadIdx.x & 63;
     // wave-uniform work item: readfirstlane makes that visible to the compiler, so everything derived from it
     // (column indices, operand addresses) lives in SGPRs and the column operands are fetched with scalar loads
@@ -54,25 +56,53 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
     const int64_t sym_from = rbase + RBROWS;  // columns at or beyond this get the transposed contribution
     // j0 and chunk are multiples of 16, so only the very last batch of the block (j1 == n) can be short
     const int64_t jfull = j0 + ((j1 - j0) / SYM_BATCH) * SYM_BATCH;
+    // Column operands are software-pipelined one column ahead: the scalar loads of column j+1 are issued before the
+    // arithmetic of column j, so their latency (and that of the table reads, which share the lgkm counter) is covered.
+    T xj[DP], aj, pj;
+    if (j0 < jfull) {
+        const int64_t j = row0 + j0;
+        aj = xa[j];
+        pj = p[j];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
+    }
     for (int64_t jb = j0; jb < jfull; jb += SYM_BATCH) {
-        const T* __restrict__ xsj = Xs + (row0 + jb) * DP;  // wave-uniform bases: the loads below are s_load with immediate offsets
+        const T* __restrict__ xsj = Xs + (row0 + jb) * DP;  // wave-uniform bases: s_load with immediate offsets
         const T* __restrict__ xaj = xa + row0 + jb;
         const T* __restrict__ pjv = p + row0 + jb;
+        const int64_t nb = (jb + SYM_BATCH < jfull) ? SYM_BATCH : 0;  // first column of the next batch (or a harmless re-read)
         T t[SYM_BATCH];
 #pragma unroll
         for (int jj = 0; jj < SYM_BATCH; ++jj) {
-            const T aj = xaj[jj];
-            const T pj = pjv[jj];
-            T xj[DP];
+            // prefetch the next column
+            T xn[DP], an, pn;
+            {
+                const int64_t o = (jj + 1 < SYM_BATCH) ? jj + 1 : nb;
+                an = xaj[o];
+                pn = pjv[o];
 #pragma unroll
-            for (int d = 0; d < DP; ++d) xj[d] = xsj[jj * DP + d];
+                for (int d = 0; d < DP; ++d) xn[d] = xsj[o * DP + d];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // issue the prefetch first; it is consumed a whole column later
+            T gram[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                T g = ai[r];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) g = tfma<T>(xi[r][d], xj[d], g);
+                gram[r] = g;
+            }
+            KappaPend<T> kp[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) kp[r] = kappa_hot_begin<T, KIND, CLAMP>(gram[r], aj, tab);
+            __builtin_amdgcn_sched_barrier(0);  // all R table reads are in flight here ...
+#pragma unroll
+            for (int r = 0; r < R; ++r) kappa_hot_poly<T, KIND>(kp[r]);
+            __builtin_amdgcn_sched_barrier(0);  // ... and are first needed here, R polynomials later
             T tj = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                T gram = ai[r];
-#pragma unroll
-                for (int d = 0; d < DP; ++d) gram = tfma<T>(xi[r][d], xj[d], gram);
-                const T kap = kappa_from_gram<T, KIND, CLAMP>(gram, aj);
+                const T kap = kappa_hot_end<T, KIND>(kp[r]);
                 acc[r] = tfma<T>(kap, pj, acc[r]);
                 tj = tfma<T>(kap, pr[r], tj);
             }
@@ -84,6 +114,10 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
             for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[r]));
             asm volatile("" : "+v"(t[jj]));
             __builtin_amdgcn_sched_barrier(0);
+            aj = an;
+            pj = pn;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) xj[d] = xn[d];
         }
         if (jb >= sym_from) {  // wave-uniform
             // transpose-reduce: after stage s the vector q holds, in lane l, the sum over the lanes that differ from l in
@@ -119,7 +153,7 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
             T gram = ai[r];
 #pragma unroll
             for (int d = 0; d < DP; ++d) gram = tfma<T>(xi[r][d], xj[d], gram);
-            const T kap = kappa_from_gram<T, KIND, CLAMP>(gram, aj);
+            const T kap = kappa_hot_from_gram<T, KIND, CLAMP>(gram, aj, tab);
             acc[r] = tfma<T>(kap, pj, acc[r]);
             tj = tfma<T>(kap, pr[r], tj);
         }
@@ -229,11 +263,11 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     T* Pcol = Prow + (int64_t)nchunk * n;
     const int grid = (nitems + 3) / 4;
     if (c->exp_clamp)
-        hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xs, (const T*)c->xa, p_full, c->r0,
-                           n, chunk, (const int2*)c->sym_items, nitems, Prow, Pcol);
+        hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full, c->r0,
+                           n, chunk, (const int2*)c->sym_items, nitems, Prow, Pcol, (const double*)c->exp_tab);
     else
-        hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xs, (const T*)c->xa, p_full, c->r0,
-                           n, chunk, (const int2*)c->sym_items, nitems, Prow, Pcol);
+        hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full, c->r0,
+                           n, chunk, (const int2*)c->sym_items, nitems, Prow, Pcol, (const double*)c->exp_tab);
     CGLB_LAUNCH_CHECK(c);
     if (c->kff_skip_combine) return CGLB_OK;
     const int cgrid = (int)((n + 255) / 256);

@@ -20,9 +20,13 @@ __global__ __launch_bounds__(256) void prep_scaled_kernel(const T* __restrict__ 
     xa[i] = (KIND == CGLB_RBF) ? T(-0.5) * s2 : s2;
 }
 
-int launch_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out) {
+// hot operand set: RBF exponent -|xh_i-xh_j|^2/2 and Matern exponent -|xh_i-xh_j| are in 1/64 octave
+double cglb_hot_scale(const cglb_ctx* c) { return (c->kind == CGLB_RBF) ? sqrt(CGLB_HOT_UNITS) : CGLB_HOT_UNITS; }
+
+int launch_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out, bool hot) {
     ScaleParams sp;
-    const double kscale = (c->kind == CGLB_RBF) ? sqrt(CGLB_LOG2E) : CGLB_SQRT3 * CGLB_LOG2E;
+    double kscale = (c->kind == CGLB_RBF) ? sqrt(CGLB_LOG2E) : CGLB_SQRT3 * CGLB_LOG2E;
+    if (hot) kscale *= cglb_hot_scale(c);
     for (int d = 0; d < CGLB_MAX_D; ++d) {
         sp.center[d] = d < c->D ? c->xmean[d] : 0.0;
         sp.scale[d] = d < c->D ? kscale / c->ls[d] : 0.0;
