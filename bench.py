@@ -94,7 +94,7 @@ def main():
     args = ap.parse_args()
 
     from cglb_amd.data import reference_init_hypers, synthetic_problem, trained_like_hypers
-    from cglb_amd.distributed import Comm, HipLocalOps, ShardedCGLB, row_partition
+    from cglb_amd.distributed import Comm, HipSymLocalOps, SymShardedCGLB, row_partition
     from cglb_amd.hip_context import HipContext
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,7 +119,8 @@ def main():
     per, parts = row_partition(N, world)
     ctx = HipContext(X, y, M, kind, device=dev, row_range=parts[rank])
     comm = Comm()
-    drv = ShardedCGLB(HipLocalOps(ctx), comm) if world > 1 else None
+    # N > 1: cyclic-symmetric scheme (each kernel value used twice, global upper triangle dealt to the ranks by 256-row blocks)
+    drv = SymShardedCGLB(HipSymLocalOps(ctx), comm) if world > 1 else None
     v = torch.zeros(N, dtype=torch.float64, device=dev)
 
     def barrier():
@@ -132,7 +133,7 @@ def main():
         if world == 1:
             v.zero_()
             return ctx.objective_and_grad(v, True, cg["max_error"], cg["max_cg_iter"], cg["restart_cg_iter"], with_grad=True)
-        drv.vbuf.zero_()
+        drv.v.zero_()
         return drv.objective_and_grad(True, cg["max_error"], cg["max_cg_iter"], cg["restart_cg_iter"], with_grad=True)
 
     def run(name, steps, warmup):
@@ -174,6 +175,8 @@ def main():
     ms_pair = ctx.time_kernel(3, reps)   # kff_matvec_kernel alone
     ms_prec = ctx.time_kernel(1, reps)   # preconditioner apply (gemv_u + triangular products + gemv_t + epilogue)
     nloc = parts[rank][1] - parts[rank][0]
+    # algorithmic pairs of one launch of the dominant kernel on this rank: all of K_ff on one GPU; with N > 1 the kernel timed
+    # here is the row-shard form (rows of this rank x all columns) that the C ABI's cglb_matvec exposes
     flops = pair_flops(kind, D) * float(N) * float(nloc)
     achieved = flops / (ms_pair * 1e-3) / 1e12
     esz = 8
@@ -213,7 +216,7 @@ def main():
             "config": {
                 "workload": f"CGLB objective+gradient, synthetic N={N} D={D} M={M} {kind} fp64, hypers={args.hypers}, cold start v=0",
                 "N": N, "D": D, "M": M, "kernel": kind, "hypers": {k: (np.asarray(val).tolist()) for k, val in hypers[args.hypers].items()},
-                "cg": cg, "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
+                "cg": cg, "parallelism": f"cyclic-symmetric K_ff blocks + column-sharded Nystrom panel x{world}" if world > 1 else "single GPU",
             },
             "cg_steps": res.steps, "cg_residual_error": res.residual_error, "bound": res.bound,
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu, "secondary": secondary,

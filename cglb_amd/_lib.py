@@ -50,6 +50,17 @@ SIGNATURES = {
     "cglb_shard_obj_phase2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cglb_shard_obj_phase3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cglb_shard_obj_finish": (c_int, [c_void_p, c_void_p, POINTER(c_double)]),
+    "cglb_set_parallel": (c_int, [c_void_p, c_int, c_int]),
+    "cglb_matvec_cyclic": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "cglb_rhs_full": (c_int, [c_void_p, c_void_p]),
+    "cglb_vec_dot": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "cglb_vec_update_v_r": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "cglb_vec_residual": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "cglb_vec_update_p": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "cglb_vec_axpy": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p]),
+    "cglb_shard_obj_phase1_kv": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "cglb_shard_obj_w": (c_int, [c_void_p, c_void_p]),
+    "cglb_shard_obj_phase3_cyclic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cglb_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cglb_get_matrix": (c_int, [c_void_p, c_int, c_void_p]),
     "cglb_time_kernel": (c_int, [c_void_p, c_int, c_int, POINTER(c_double)]),

@@ -310,7 +310,7 @@ int obj_phase2(cglb_ctx* c, const void* v_full, const void* u, double* sc_partia
 }
 
 template <typename T>
-int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const void* aw, double* out) {
+int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const void* aw, double* out, const void* u_full_cyclic = nullptr) {
     const int M = c->M, D = c->D;
     const size_t glen = (size_t)CGLB_GRAD_LEN(D, M);
     const double s = c->noise, f = c->var, sigma = std::sqrt(s), tau = tau_of(c);
@@ -336,11 +336,18 @@ int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const voi
         BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, (int)c->nloc, M, M, &one, (const T*)c->At, (int)c->lda,
                             (const T*)c->Mtmp2, M, &zero, (T*)c->Guf, (int)c->lda));
         CGLB_TRY(launch_grad_kuf(c, c->w_t2, c->w_z, out));
-        // u = w + v/2 ; N^2 bilinear pass
-        const T* v_loc = (const T*)v_full + c->r0;
-        hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid1d(c->nloc)), dim3(256), 0, c->stream, (T*)c->w_Ap, (T)1, (const T*)c->w_z, (T)0.5, v_loc,
-                           c->nloc);
-        CGLB_TRY(launch_grad_kff(c, v_full, c->w_Ap, c->scal + S_TMP2));
+        if (!u_full_cyclic) {
+            // u = w + v/2 ; N^2 bilinear pass over the local rows
+            const T* v_loc = (const T*)v_full + c->r0;
+            hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid1d(c->nloc)), dim3(256), 0, c->stream, (T*)c->w_Ap, (T)1, (const T*)c->w_z, (T)0.5, v_loc,
+                               c->nloc);
+            CGLB_TRY(launch_grad_kff(c, v_full, c->w_Ap, c->scal + S_TMP2));
+            hipLaunchKernelGGL((axpby_kernel<double>), dim3(1), dim3(64), 0, c->stream, out, 1.0, (const double*)out, 1.0,
+                               (const double*)(c->scal + S_TMP2), (int64_t)D);
+        }
+    }
+    if (u_full_cyclic) {  // this rank's cyclic share of the global symmetric N^2 form (u gathered by the caller)
+        CGLB_TRY(launch_grad_kff_cyclic(c, v_full, u_full_cyclic, c->scal + S_TMP2));
         hipLaunchKernelGGL((axpby_kernel<double>), dim3(1), dim3(64), 0, c->stream, out, 1.0, (const double*)out, 1.0,
                            (const double*)(c->scal + S_TMP2), (int64_t)D);
     }
@@ -557,6 +564,13 @@ int cglb_shard_rhs(cglb_ctx* c, void* out_local) {
     return launch_sub_scalar(c, out_local, (const char*)c->y + (size_t)c->r0 * c->esz, c->mean, c->nloc);
 }
 
+int cglb_rhs_full(cglb_ctx* c, void* out_full) {
+    if (!c || !out_full) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede rhs");
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_sub_scalar(c, out_full, c->y, c->mean, c->N);
+}
+
 int cglb_cross_matvec(cglb_ctx* c, const void* xnew, int64_t n_new, const void* v_full, void* out) {
     if (!c || !xnew || !v_full || !out || n_new < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
     if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede cross_matvec");
@@ -620,6 +634,67 @@ int cglb_shard_update_p(cglb_ctx* c, void* p_local, const void* z_local, const v
     if (!c || !p_local || !z_local || !new_rz || !rz) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     HIP_CHECK(c, hipSetDevice(c->device));
     return launch_update_p(c, p_local, z_local, (const double*)new_rz, (const double*)rz, restart);
+}
+
+// ---- cyclic-symmetric multi-GPU path (include/cglb_hip.h) ---------------------------------------------------------
+int cglb_set_parallel(cglb_ctx* c, int world, int rank) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad world/rank") : CGLB_ERR_BAD_ARG;
+    c->par_world = world;
+    c->par_rank = rank;
+    return CGLB_OK;
+}
+int cglb_matvec_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial) {
+    if (!c || !p_full || !out_full_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede matvec");
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_kff_sym_cyclic(c, p_full, out_full_partial);
+}
+int cglb_vec_dot(cglb_ctx* c, int64_t n, const void* a, const void* b, void* out) {
+    if (!c || !a || !b || !out || n < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_dot(c, a, b, n, (double*)out);
+}
+int cglb_vec_update_v_r(cglb_ctx* c, int64_t n, void* v, void* r, const void* p, const void* Ap, const void* rz, const void* pAp, int update_r) {
+    if (!c || !v || !r || !p || !Ap || !rz || !pAp || n < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_update_v_r(c, v, r, p, Ap, (const double*)rz, (const double*)pAp, update_r, n);
+}
+int cglb_vec_residual(cglb_ctx* c, int64_t n, void* r, const void* b, const void* Kv) {
+    if (!c || !r || !b || !Kv || n < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_residual(c, r, b, Kv, n);
+}
+int cglb_vec_update_p(cglb_ctx* c, int64_t n, void* p, const void* z, const void* new_rz, const void* rz, int restart) {
+    if (!c || !p || !z || !new_rz || !rz || n < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_update_p(c, p, z, (const double*)new_rz, (const double*)rz, restart, n);
+}
+int cglb_vec_axpy(cglb_ctx* c, int64_t n, double alpha, const void* x, void* y) {
+    if (!c || !x || !y || n < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_axpy(c, y, alpha, x, n);
+}
+int cglb_shard_obj_phase1_kv(cglb_ctx* c, const void* Kv_local, void* u_partial) {
+    if (!c || !Kv_local || !u_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    const char* y_loc = (const char*)c->y + (size_t)c->r0 * c->esz;
+    CGLB_TRY(launch_sub_scalar(c, c->w_e, y_loc, c->mean, c->nloc));
+    HIP_CHECK(c, hipMemcpyAsync(c->w_Kv, Kv_local, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
+    CGLB_TRY(launch_residual(c, c->w_r, c->w_e, c->w_Kv));
+    return launch_gemv_u(c, c->w_r, u_partial);
+}
+int cglb_shard_obj_w(cglb_ctx* c, void* w_local_out) {
+    if (!c || !w_local_out) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    HIP_CHECK(c, hipMemcpyAsync(w_local_out, c->w_z, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
+    return CGLB_OK;
+}
+int cglb_shard_obj_phase3_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, const void* sc, const void* aw, void* grad_partial) {
+    if (!c || !v_full || !u_full || !sc || !aw || !grad_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_DISPATCH_T(c->dtype, return obj_phase3_impl<T>(c, v_full, (const double*)sc, aw, (double*)grad_partial, u_full));
 }
 
 int cglb_pcg_solve(cglb_ctx* c, const void* b, void* v_inout, double max_error, int max_cg_iter, int restart_cg_iter, int* steps, double* half_rz) {

@@ -48,7 +48,8 @@ struct cglb_ctx {
     size_t frag_cap = 0;
     void* sym_items = nullptr;       // work list (row block, column chunk) of the symmetric mat-vec
     int64_t sym_n = -1, sym_chunk = 0, sym_chunk_opt = 0;
-    int sym_rbrows = 0, sym_nitems = 0;
+    int sym_rbrows = 0, sym_nitems = 0, sym_world = 1, sym_rank = 0;
+    int par_world = 1, par_rank = 0;  // cyclic distribution of the symmetric K_ff work over ranks (cglb_set_parallel)
     void* slabs = nullptr;   // split-K partial A A^T slabs [nslab][M][M]
     size_t slab_cap = 0;
     rocblas_int* info_dev = nullptr;
@@ -120,14 +121,17 @@ int launch_kuu(cglb_ctx* c);  // Lc <- Kuu + jitter I (full symmetric)
 int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
 int launch_frag_prep(cglb_ctx* c);
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
+int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial);  // this rank's share of the global upper triangle
+int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, double* out_dl);
 int launch_kff_plain_range(cglb_ctx* c, const void* p_full, int64_t col0, int64_t col1, void* part, int64_t* nslots);
 int launch_kff_mfma_pairs(cglb_ctx* c, const double* p_full, int64_t* jsplit_out);
 int launch_cross_matvec(cglb_ctx* c, const void* Xs_new, const void* xa_new, int64_t n_new, const void* v_full, void* out);
 // kernels_vec.hip
 int launch_dot(cglb_ctx* c, const void* a, const void* b, int64_t n, double* out_slot);
-int launch_update_v_r(cglb_ctx* c, void* v, void* r, const void* p, const void* Ap, const double* rz, const double* pAp, int update_r);
-int launch_residual(cglb_ctx* c, void* r, const void* b, const void* Kv);
-int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart);
+int launch_update_v_r(cglb_ctx* c, void* v, void* r, const void* p, const void* Ap, const double* rz, const double* pAp, int update_r, int64_t n = -1);
+int launch_residual(cglb_ctx* c, void* r, const void* b, const void* Kv, int64_t n = -1);
+int launch_axpy(cglb_ctx* c, void* y, double alpha, const void* x, int64_t n);
+int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart, int64_t n = -1);
 int launch_gemv_u(cglb_ctx* c, const void* r_local, void* u_out);               // u = A_loc r
 int launch_tri_apply(cglb_ctx* c, const void* u, void* t_out);                  // t = LB^-T LB^-1 u
 int launch_precond_z(cglb_ctx* c, const void* r_local, const void* t, void* z_local, double* rz_slot);

@@ -22,11 +22,12 @@ template <typename T, int KIND, int DP, int R, bool SYM>
 __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsRow, const T* __restrict__ uRow, const T* __restrict__ vRow,
                                                        int64_t nrows, const T* __restrict__ XsCol, const T* __restrict__ vCol,
                                                        const T* __restrict__ uCol, int64_t ncols, int64_t jchunk, int64_t blk0,
-                                                       double* __restrict__ part, const double* __restrict__ exp_tab) {
+                                                       int rb_stride, int rb_offset, double* __restrict__ part,
+                                                       const double* __restrict__ exp_tab) {
     __shared__ double smem[16];
     __shared__ double tab[64];
     load_exp_table(tab, exp_tab);
-    const int64_t rblock = (int64_t)blockIdx.x * (256 * R);
+    const int64_t rblock = ((int64_t)blockIdx.x * rb_stride + rb_offset) * (256 * R);  // cyclic over ranks when rb_stride > 1
     const int64_t rbase = rblock + threadIdx.x;
     T xi[R][DP], acc[R][DP], ui[R], vi[R];
 #pragma unroll
@@ -143,13 +144,51 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
 #define GK_LAUNCH(RR, SYMV)                                                                                                        \
     hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, SYMV>), grid, dim3(256), 0, c->stream, (const T*)c->Xh + c->r0 * DP,        \
                        (const T*)u_local, (const T*)v_full + c->r0, c->nloc, (const T*)c->Xh + r.col0 * DP, (const T*)v_full + r.col0, \
-                       (const T*)u_local, r.ncols, r.jchunk, blk0, c->gpart, (const double*)c->exp_tab)
+                       (const T*)u_local, r.ncols, r.jchunk, blk0, 1, 0, c->gpart, (const double*)c->exp_tab)
         if (r.sym) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); }); }
         else { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); }); }
 #undef GK_LAUNCH
         CGLB_LAUNCH_CHECK(c);
         blk0 += bx * r.jsplit;
     }
+    hipLaunchKernelGGL(grad_dl_finalize_kernel, dim3(c->D), dim3(256), 0, c->stream, (const double*)c->gpart, nblk, c->Dp, c->D, sp,
+                       c->var, out_dl, 0);
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
+// Cyclic form for the multi-GPU path: the whole N x N form in its symmetric version, row blocks rb == par_rank (mod par_world).
+// u_full, v_full: all N entries.  out_dl (device double[D], overwritten) is this rank's PARTIAL sum (all-reduced by the caller).
+int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, double* out_dl) {
+    ScaleParams sp;
+    const double ks = kscale_of(c) * cglb_hot_scale(c);
+    for (int d = 0; d < CGLB_MAX_D; ++d) {
+        sp.center[d] = 0;
+        sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
+    }
+    const int R = c->Dp <= 8 ? 2 : 1;
+    const int64_t nb = (c->N + 256 * R - 1) / (256 * R);
+    const int64_t bx = c->par_rank < nb ? (nb - c->par_rank + c->par_world - 1) / c->par_world : 0;
+    if (bx == 0) {
+        HIP_CHECK(c, hipMemsetAsync(out_dl, 0, sizeof(double) * c->D, c->stream));
+        return CGLB_OK;
+    }
+    int64_t js = 2 * ((8192 + bx - 1) / bx);
+    if (js > 1024) js = 1024;
+    if (js > (c->N + 63) / 64) js = (c->N + 63) / 64;
+    if (js < 1) js = 1;
+    const int64_t jchunk = (c->N + js - 1) / js;
+    const int64_t jsplit = (c->N + jchunk - 1) / jchunk;
+    const int64_t nblk = bx * jsplit;
+    CGLB_TRY(ensure_gpart(c, (size_t)nblk * c->Dp * sizeof(double)));
+    dim3 grid((unsigned)bx, (unsigned)jsplit);
+#define GKC_LAUNCH(RR)                                                                                                            \
+    hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, true>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)u_full,  \
+                       (const T*)v_full, c->N, (const T*)c->Xh, (const T*)v_full, (const T*)u_full, c->N, jchunk, (int64_t)0,       \
+                       c->par_world, c->par_rank, c->gpart, (const double*)c->exp_tab)
+    CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); });
+#undef GKC_LAUNCH
+    CGLB_LAUNCH_CHECK(c);
     hipLaunchKernelGGL(grad_dl_finalize_kernel, dim3(c->D), dim3(256), 0, c->stream, (const double*)c->gpart, nblk, c->Dp, c->D, sp,
                        c->var, out_dl, 0);
     CGLB_LAUNCH_CHECK(c);

@@ -25,7 +25,8 @@
 template <typename T, int KIND, int DP, int R, bool CLAMP>
 __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items, int nitems,
-                                                      T* __restrict__ Prow, T* __restrict__ Pcol, const double* __restrict__ exp_tab) {
+                                                      int rb_stride, T* __restrict__ Prow, T* __restrict__ Pcol,
+                                                      const double* __restrict__ exp_tab) {
     __shared__ double tab[64];
     load_exp_table(tab, exp_tab);  // before the early exit below: every thread reaches the barrier inside
     const int lane = threadIdx.x & 63;
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
     if (item >= nitems) return;  // whole wave exits together
     const int2 it = items[item];
     const int64_t rb = __builtin_amdgcn_readfirstlane(it.x), k = __builtin_amdgcn_readfirstlane(it.y);
+    const int64_t cslot = rb / rb_stride;  // compact Pcol slot: with a cyclic rank distribution only every rb_stride-th block is here
     constexpr int RBROWS = 64 * R;
     const int64_t rbase = rb * RBROWS;
     T xi[R][DP], ai[R], pr[R], acc[R];
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
             T v = t[0];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (lane < SYM_BATCH) Pcol[rb * n + jb + lane] = v;
+            if (lane < SYM_BATCH) Pcol[cslot * n + jb + lane] = v;
         }
     }
     // ragged tail of the block (fewer than 16 columns): one column at a time, plain wave reduction
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
         }
         if (jc >= sym_from) {
             const T v = wave_sum(tj);
-            if (lane == 0) Pcol[rb * n + jc] = v;
+            if (lane == 0) Pcol[cslot * n + jc] = v;
         }
     }
 #pragma unroll
@@ -170,10 +172,13 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
 }
 
 // out[i] = var * ( sum_s plain[s][i] + sum_{k >= k0(i)} Prow[k][i] + sum_{rb < rb(i)} Pcol[rb][i] ) + noise * pdiag[i]
+// With a cyclic distribution (world > 1) only the row blocks rb == rank (mod world) were processed here: row sums exist for
+// the rows of those blocks, column sums come from those blocks only, and the noise term is left to the caller (pdiag == null).
 template <typename T>
 __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restrict__ plain, int nplain, const T* __restrict__ Prow, int nchunk,
-                                                              const T* __restrict__ Pcol, int64_t n, int64_t chunk, int rbrows, T var, T noise,
-                                                              const T* __restrict__ pdiag, T* __restrict__ out, double* __restrict__ dotpart) {
+                                                              const T* __restrict__ Pcol, int64_t n, int64_t chunk, int rbrows, int world, int rank,
+                                                              T var, T noise, const T* __restrict__ pdiag, T* __restrict__ out,
+                                                              double* __restrict__ dotpart) {
     __shared__ double smem[16];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double contrib = 0.0;
@@ -181,12 +186,16 @@ __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restric
         T s = 0;
         for (int q = 0; q < nplain; ++q) s += plain[(int64_t)q * n + i];
         const int64_t rbi = i / rbrows;
-        const int64_t k0 = (rbi * rbrows) / chunk;
-        for (int64_t k = k0; k < nchunk; ++k) s += Prow[k * n + i];
-        for (int64_t rb = 0; rb < rbi; ++rb) s += Pcol[rb * n + i];
+        if (rbi % world == rank) {
+            const int64_t k0 = (rbi * rbrows) / chunk;
+            for (int64_t k = k0; k < nchunk; ++k) s += Prow[k * n + i];
+        }
+        for (int64_t rb = rank; rb < rbi; rb += world) s += Pcol[(rb / world) * n + i];
         T o = var * s;
-        o = tfma<T>(noise, pdiag[i], o);
-        contrib = (double)pdiag[i] * (double)o;
+        if (pdiag) {
+            o = tfma<T>(noise, pdiag[i], o);
+            contrib = (double)pdiag[i] * (double)o;
+        }
         out[i] = o;
     }
     if (dotpart) {
@@ -204,43 +213,52 @@ __global__ __launch_bounds__(256) void finalize_sum_sym_kernel(const double* __r
 }
 
 
-static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, int* nitems_out, int* nrb_out, int* nchunk_out) {
+static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, int world, int rank, int* nitems_out, int* nrb_out,
+                            int* nchunk_out) {
     const int nrb = (int)((n + rbrows - 1) / rbrows);
     const int nchunk = (int)((n + chunk - 1) / chunk);
-    if (c->sym_items && c->sym_n == n && c->sym_rbrows == rbrows && c->sym_chunk == chunk) {
+    if (c->sym_items && c->sym_n == n && c->sym_rbrows == rbrows && c->sym_chunk == chunk && c->sym_world == world && c->sym_rank == rank) {
         *nitems_out = c->sym_nitems; *nrb_out = nrb; *nchunk_out = nchunk;
         return CGLB_OK;
     }
     std::vector<int2> items;
     // longest rows first (row block 0 sweeps the most columns): helps the tail of the launch
-    for (int rb = 0; rb < nrb; ++rb) {
+    for (int rb = rank; rb < nrb; rb += world) {
         const int k0 = (int)(((int64_t)rb * rbrows) / chunk);
         for (int k = k0; k < nchunk; ++k) items.push_back(make_int2(rb, k));
     }
     if (c->sym_items) HIP_CHECK(c, hipFree(c->sym_items));
     c->sym_items = nullptr;
+    if (items.empty()) items.push_back(make_int2(0, 0));  // keep the allocation non-empty; nitems stays 0
     HIP_CHECK(c, hipMalloc(&c->sym_items, items.size() * sizeof(int2)));
     HIP_CHECK(c, hipMemcpyAsync(c->sym_items, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    c->sym_n = n; c->sym_rbrows = rbrows; c->sym_chunk = chunk; c->sym_nitems = (int)items.size();
+    c->sym_n = n; c->sym_rbrows = rbrows; c->sym_chunk = chunk; c->sym_world = world; c->sym_rank = rank;
+    c->sym_nitems = (rank < nrb) ? (int)items.size() : 0;
     *nitems_out = c->sym_nitems; *nrb_out = nrb; *nchunk_out = nchunk;
     return CGLB_OK;
 }
 
+// cyclic == false: the square block of the local row shard [r0, r1) plus plain kernels for the off-diagonal ranges.
+// cyclic == true : the whole N x N upper triangle, row blocks rb == par_rank (mod par_world); output is a full-N PARTIAL vector
+//                  (var * sums, no noise term) that the caller all-reduces.
 template <typename T, int KIND, int DP>
-static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* pdot_slot) {
+static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* pdot_slot, bool cyclic) {
     constexpr int R = (DP <= 8) ? 4 : (DP <= 16 ? 2 : 1);
     constexpr int RBROWS = 64 * R;
-    const int64_t n = c->nloc;
+    const int64_t n = cyclic ? c->N : c->nloc;
+    const int64_t row0 = cyclic ? 0 : c->r0;
+    const int world = cyclic ? c->par_world : 1, rank = cyclic ? c->par_rank : 0;
     int64_t chunk = c->sym_chunk_opt > 0 ? c->sym_chunk_opt : 1024;
     chunk = (chunk + SYM_BATCH - 1) / SYM_BATCH * SYM_BATCH;
     int nitems = 0, nrb = 0, nchunk = 0;
-    CGLB_TRY(ensure_sym_items(c, n, RBROWS, chunk, &nitems, &nrb, &nchunk));
+    CGLB_TRY(ensure_sym_items(c, n, RBROWS, chunk, world, rank, &nitems, &nrb, &nchunk));
+    const int ncslot = (nrb + world - 1) / world;
     // off-diagonal column ranges of the row shard ([0,r0) and [r1,N)) go through the plain kernel
-    const int64_t nleft = c->r0, nright = c->N - c->r1;
+    const int64_t nleft = cyclic ? 0 : c->r0, nright = cyclic ? 0 : c->N - c->r1;
     int64_t plain_slots_max = 0;
     if (nleft > 0 || nright > 0) plain_slots_max = 2 * 512;
-    const size_t need = ((size_t)plain_slots_max + nchunk + nrb) * n * sizeof(T);
+    const size_t need = ((size_t)plain_slots_max + nchunk + ncslot) * n * sizeof(T);
     if (need > c->kpart_cap) {
         if (c->kpart) HIP_CHECK(c, hipFree(c->kpart));
         c->kpart = nullptr;
@@ -262,18 +280,21 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     T* Prow = plain + nplain * n;
     T* Pcol = Prow + (int64_t)nchunk * n;
     const int grid = (nitems + 3) / 4;
-    if (c->exp_clamp)
-        hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full, c->r0,
-                           n, chunk, (const int2*)c->sym_items, nitems, Prow, Pcol, (const double*)c->exp_tab);
-    else
-        hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full, c->r0,
-                           n, chunk, (const int2*)c->sym_items, nitems, Prow, Pcol, (const double*)c->exp_tab);
-    CGLB_LAUNCH_CHECK(c);
+    if (grid > 0) {
+        if (c->exp_clamp)
+            hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full,
+                               row0, n, chunk, (const int2*)c->sym_items, nitems, world, Prow, Pcol, (const double*)c->exp_tab);
+        else
+            hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full,
+                               row0, n, chunk, (const int2*)c->sym_items, nitems, world, Prow, Pcol, (const double*)c->exp_tab);
+        CGLB_LAUNCH_CHECK(c);
+    }
     if (c->kff_skip_combine) return CGLB_OK;
     const int cgrid = (int)((n + 255) / 256);
     if (pdot_slot && cgrid > DOTPART_CAP) return cglb_fail(c, CGLB_ERR_BAD_ARG, "row shard too large for dot partials");
     hipLaunchKernelGGL((kff_sym_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)plain, (int)nplain, (const T*)Prow, nchunk,
-                       (const T*)Pcol, n, chunk, RBROWS, (T)c->var, (T)c->noise, p_full + c->r0, out_local, pdot_slot ? c->dotpart : nullptr);
+                       (const T*)Pcol, n, chunk, RBROWS, world, rank, (T)c->var, (T)c->noise, cyclic ? (const T*)nullptr : p_full + c->r0, out_local,
+                       pdot_slot ? c->dotpart : nullptr);
     CGLB_LAUNCH_CHECK(c);
     if (pdot_slot) {
         hipLaunchKernelGGL(finalize_sum_sym_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, cgrid, pdot_slot);
@@ -283,6 +304,11 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
 }
 
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot) {
-    CGLB_DISPATCH_ALL(c, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out_local, pdot_slot)));
+    CGLB_DISPATCH_ALL(c, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out_local, pdot_slot, false)));
+    return CGLB_OK;
+}
+
+int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial) {
+    CGLB_DISPATCH_ALL(c, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out_full_partial, nullptr, true)));
     return CGLB_OK;
 }

@@ -55,11 +55,12 @@ __global__ __launch_bounds__(256) void update_v_r_kernel(T* __restrict__ v, T* _
 }
 
 int launch_update_v_r(cglb_ctx* c, void* v, void* r, const void* p, const void* Ap, const double* rz, const double* pAp,
-                      int update_r) {
-    if (c->nloc == 0) return CGLB_OK;
-    const int grid = vec_grid(c->nloc, 256);
+                      int update_r, int64_t n) {
+    if (n < 0) n = c->nloc;
+    if (n == 0) return CGLB_OK;
+    const int grid = vec_grid(n, 256);
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((update_v_r_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (T*)v, (T*)r,
-                                                 (const T*)p, (const T*)Ap, c->nloc, rz, pAp, update_r));
+                                                 (const T*)p, (const T*)Ap, n, rz, pAp, update_r));
     CGLB_LAUNCH_CHECK(c);
     return CGLB_OK;
 }
@@ -71,11 +72,12 @@ __global__ __launch_bounds__(256) void residual_kernel(T* __restrict__ r, const 
         r[i] = b[i] - Kv[i];
 }
 
-int launch_residual(cglb_ctx* c, void* r, const void* b, const void* Kv) {
-    if (c->nloc == 0) return CGLB_OK;
-    const int grid = vec_grid(c->nloc, 256);
+int launch_residual(cglb_ctx* c, void* r, const void* b, const void* Kv, int64_t n) {
+    if (n < 0) n = c->nloc;
+    if (n == 0) return CGLB_OK;
+    const int grid = vec_grid(n, 256);
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((residual_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (T*)r, (const T*)b,
-                                                 (const T*)Kv, c->nloc));
+                                                 (const T*)Kv, n));
     CGLB_LAUNCH_CHECK(c);
     return CGLB_OK;
 }
@@ -89,11 +91,26 @@ __global__ __launch_bounds__(256) void update_p_kernel(T* __restrict__ p, const 
         p[i] = restart ? z[i] : tfma<T>(beta, p[i], z[i]);
 }
 
-int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart) {
-    if (c->nloc == 0) return CGLB_OK;
-    const int grid = vec_grid(c->nloc, 256);
+int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart, int64_t n) {
+    if (n < 0) n = c->nloc;
+    if (n == 0) return CGLB_OK;
+    const int grid = vec_grid(n, 256);
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((update_p_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (T*)p, (const T*)z,
-                                                 c->nloc, new_rz, rz, restart));
+                                                 n, new_rz, rz, restart));
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
+// ---- y += alpha x  (adds the noise * p diagonal term to an all-reduced K_ff p) ----------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void axpy_kernel(T* __restrict__ y, T alpha, const T* __restrict__ x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = tfma<T>(alpha, x[i], y[i]);
+}
+int launch_axpy(cglb_ctx* c, void* y, double alpha, const void* x, int64_t n) {
+    if (n == 0) return CGLB_OK;
+    const int grid = vec_grid(n, 256);
+    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((axpy_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (T*)y, (T)alpha, (const T*)x, n));
     CGLB_LAUNCH_CHECK(c);
     return CGLB_OK;
 }

@@ -242,3 +242,156 @@ class ShardedCGLB:
             grad = self.grad.detach().cpu().numpy().copy()
         bound, lower, upper, logdet = ops.obj_finish(self.sc)
         return ShardedResult(bound, lower, upper, logdet, steps, half, grad)
+
+
+# =====================================================================================================================
+# Cyclic-symmetric scheme: keeps the factor 2 of the symmetric pair kernel under sharding.
+# =====================================================================================================================
+class SymLocalOps(LocalOps):
+    """Additional local operations of the cyclic-symmetric driver (see SymShardedCGLB)."""
+
+    noise: float
+
+    def set_parallel(self, world: int, rank: int): raise NotImplementedError
+    def rhs_full(self, out_full): raise NotImplementedError
+    def matvec_cyclic(self, p_full, out_full_partial): raise NotImplementedError
+    def vec_dot(self, n, a, b, out): raise NotImplementedError
+    def vec_update_v_r(self, n, v, r, p, Ap, rz, pAp, update_r: bool): raise NotImplementedError
+    def vec_residual(self, n, r, b, Kv): raise NotImplementedError
+    def vec_update_p(self, n, p, z, new_rz, rz, restart: bool): raise NotImplementedError
+    def vec_axpy(self, n, alpha, x, y): raise NotImplementedError
+    def obj_phase1_kv(self, Kv_local, u_out): raise NotImplementedError
+    def obj_w(self, w_local_out): raise NotImplementedError
+    def obj_phase3_cyclic(self, v_full, u_full, sc, aw, grad_out): raise NotImplementedError
+
+
+class HipSymLocalOps(HipLocalOps, SymLocalOps):
+    @property
+    def noise(self):
+        return self.ctx.noise
+
+    def set_parallel(self, world, rank): self._ck(self.lib.cglb_set_parallel(self.h, int(world), int(rank)))
+    def rhs_full(self, out_full): self._ck(self.lib.cglb_rhs_full(self.h, self._p(out_full)))
+    def matvec_cyclic(self, p_full, out): self._ck(self.lib.cglb_matvec_cyclic(self.h, self._p(p_full), self._p(out)))
+    def vec_dot(self, n, a, b, out): self._ck(self.lib.cglb_vec_dot(self.h, int(n), self._p(a), self._p(b), self._p(out)))
+    def vec_update_v_r(self, n, v, r, p, Ap, rz, pAp, update_r): self._ck(self.lib.cglb_vec_update_v_r(self.h, int(n), self._p(v), self._p(r), self._p(p), self._p(Ap), self._p(rz), self._p(pAp), int(update_r)))
+    def vec_residual(self, n, r, b, Kv): self._ck(self.lib.cglb_vec_residual(self.h, int(n), self._p(r), self._p(b), self._p(Kv)))
+    def vec_update_p(self, n, p, z, new_rz, rz, restart): self._ck(self.lib.cglb_vec_update_p(self.h, int(n), self._p(p), self._p(z), self._p(new_rz), self._p(rz), int(restart)))
+    def vec_axpy(self, n, alpha, x, y): self._ck(self.lib.cglb_vec_axpy(self.h, int(n), float(alpha), self._p(x), self._p(y)))
+    def obj_phase1_kv(self, Kv_local, u_out): self._ck(self.lib.cglb_shard_obj_phase1_kv(self.h, self._p(Kv_local), self._p(u_out)))
+    def obj_w(self, w_local_out): self._ck(self.lib.cglb_shard_obj_w(self.h, self._p(w_local_out)))
+    def obj_phase3_cyclic(self, v_full, u_full, sc, aw, grad_out): self._ck(self.lib.cglb_shard_obj_phase3_cyclic(self.h, self._p(v_full), self._p(u_full), self._p(sc), self._p(aw), self._p(grad_out)))
+
+
+class SymShardedCGLB:
+    """Multi-GPU evaluation with the symmetric K_ff work dealt cyclically over the ranks.
+
+    * K_ff p: every rank evaluates the (row block, column chunk) cells of the GLOBAL upper triangle whose 256-row block index
+      is == rank (mod world), using each kernel value for both out_i and out_j, and produces a full-length partial vector;
+      one all-reduce (N elements) gives every rank the full product.  Work per rank is N^2/(2G) pair evaluations, against
+      ~N^2/G for row sharding (where only the diagonal block of a shard is symmetric).
+    * p, Ap, v, r, b live in full on every rank; their O(N) updates are done redundantly (identical inputs, identical
+      kernels -> identical bits, so all ranks take the same branch of the stop test).
+    * The Nystrom panel A stays column-sharded over contiguous rows [r0, r1): u = A r is all-reduced (M elements) and the
+      preconditioned residual z is all-gathered (N/G elements per rank).
+    Collectives per PCG iteration: all-reduce(N), all-reduce(M), all-gather(N/G) — three instead of four, no scalar ones.
+    """
+
+    def __init__(self, ops: SymLocalOps, comm: Optional[Comm] = None):
+        self.ops = ops
+        self.comm = comm if comm is not None else Comm()
+        self.N, self.M, self.D = ops.N, ops.M, ops.D
+        G = self.comm.world
+        self.per, parts = row_partition(self.N, G)
+        r0, r1 = parts[self.comm.rank]
+        if (ops.r0, ops.r1) != (r0, r1):
+            raise ValueError(f"rank {self.comm.rank}: local ops own rows [{ops.r0},{ops.r1}) but the partition says [{r0},{r1})")
+        self.r0, self.r1, self.nloc = r0, r1, r1 - r0
+        dev, dt = ops.device, ops.dtype
+        z = lambda n, d=dt: torch.zeros(max(n, 1), dtype=d, device=dev)
+        N, per = self.N, self.per
+        self.v, self.p, self.r, self.Ap, self.Kv, self.b = z(N), z(N), z(N), z(N), z(N), z(N)
+        self.zbuf, self.ubuf = z(G * per), z(G * per)   # all-gather targets (padded to equal slices)
+        self.u, self.aw = z(self.M), z(self.M)
+        self.rz, self.rz_new, self.pAp, self.scratch = z(1, torch.float64), z(1, torch.float64), z(1, torch.float64), z(1, torch.float64)
+        self.sc = z(8, torch.float64)
+        self.grad = z(self.D + 3 + self.M * self.D, torch.float64)
+        ops.set_parallel(G, self.comm.rank)
+
+    def _own(self, buf):
+        return buf[self.comm.rank * self.per: self.comm.rank * self.per + self.nloc]
+
+    def v_full(self):
+        return self.v
+
+    def setup(self):
+        self.ops.setup_local()
+        if self.comm.world > 1:
+            self.comm.allreduce(self.ops.aat_tensor())
+        self.ops.setup_finish()
+
+    def matvec(self, x_full, out_full):
+        """out = (K_ff + noise I) x, full length on every rank."""
+        self.ops.matvec_cyclic(x_full, out_full)
+        self.comm.allreduce(out_full)
+        self.ops.vec_axpy(self.N, self.ops.noise, x_full, out_full)
+
+    def _precond(self, rz_out):
+        """z = P r (full, gathered into zbuf[:N]); rz_out = r^T z."""
+        ops = self.ops
+        r_loc = self.r[self.r0:self.r1]
+        ops.precond_u(r_loc, self.u)
+        self.comm.allreduce(self.u)
+        ops.precond_z(r_loc, self.u, self._own(self.zbuf), self.scratch)
+        self.comm.allgather_inplace(self.zbuf, self.per)
+        ops.vec_dot(self.N, self.r, self.zbuf[: self.N], rz_out)
+
+    def pcg(self, max_error=1.0, max_cg_iter=100, restart_cg_iter=40) -> Tuple[int, float]:
+        """conjugate_gradient.py:41-86 on replicated full vectors; v is updated in place."""
+        ops, N = self.ops, self.N
+        zf = self.zbuf[:N]
+        ops.rhs_full(self.b)
+        self.matvec(self.v, self.Kv)                               # :57
+        ops.vec_residual(N, self.r, self.b, self.Kv)               # :58
+        self._precond(self.rz)                                     # :59
+        ops.vec_update_p(N, self.p, zf, self.rz, self.rz, True)    # :61
+        rz = float(self.rz.item())
+        i = 0
+        while 0.5 * rz > max_error and i < max_cg_iter:            # :65
+            self.matvec(self.p, self.Ap)                           # :66
+            ops.vec_dot(N, self.p, self.Ap, self.pAp)              # :67
+            restart = restart_cg_iter > 0 and (i % restart_cg_iter == restart_cg_iter - 1)  # :70
+            ops.vec_update_v_r(N, self.v, self.r, self.p, self.Ap, self.rz, self.pAp, not restart)  # :68, :72
+            if restart:
+                self.matvec(self.v, self.Kv)
+                ops.vec_residual(N, self.r, self.b, self.Kv)
+            self._precond(self.rz_new)                             # :73
+            ops.vec_update_p(N, self.p, zf, self.rz_new, self.rz, restart)  # :75
+            self.rz.copy_(self.rz_new)                             # :76
+            rz = float(self.rz.item())
+            i += 1
+        return i, 0.5 * rz
+
+    def objective_and_grad(self, run_cg=True, max_error=1.0, max_cg_iter=100, restart_cg_iter=40, with_grad=True) -> ShardedResult:
+        ops, comm = self.ops, self.comm
+        self.setup()
+        steps, half = 0, float("nan")
+        if run_cg:
+            steps, half = self.pcg(max_error, max_cg_iter, restart_cg_iter)
+        self.matvec(self.v, self.Kv)                                          # models.py:280
+        ops.obj_phase1_kv(self.Kv[self.r0:self.r1], self.u)
+        comm.allreduce(self.u)
+        ops.obj_phase2(self.v, self.u, self.sc, self.aw)
+        comm.allreduce(self.sc)
+        grad = None
+        if with_grad:
+            comm.allreduce(self.aw)
+            u_loc = self._own(self.ubuf)
+            ops.obj_w(u_loc)                                                   # w = P r (local slice)
+            ops.vec_axpy(self.nloc, 0.5, self.v[self.r0:self.r1], u_loc)       # u = w + v/2
+            comm.allgather_inplace(self.ubuf, self.per)
+            ops.obj_phase3_cyclic(self.v, self.ubuf[: self.N], self.sc, self.aw, self.grad)
+            comm.allreduce(self.grad)
+            grad = self.grad.detach().cpu().numpy().copy()
+        bound, lower, upper, logdet = ops.obj_finish(self.sc)
+        return ShardedResult(bound, lower, upper, logdet, steps, half, grad)

@@ -99,6 +99,7 @@ class HipContext:
                                       float(mean), _ptr(Zd), float(jitter))
         _lib.check(rc, self._ctx)
         torch.cuda.synchronize(self.device)
+        self.noise = float(noise)
 
     def setup(self):
         _lib.check(self.lib.cglb_setup(self._ctx), self._ctx)

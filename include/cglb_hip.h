@@ -131,6 +131,27 @@ int cglb_shard_obj_phase3(cglb_ctx* ctx, const void* v_full, const void* sc /* d
                           const void* aw /* dev [m], reduced */, void* grad_partial /* dev double[GRAD_LEN] */);
 int cglb_shard_obj_finish(cglb_ctx* ctx, const void* sc /* dev double[8], reduced */, double* out4);
 
+/* ---- cyclic-symmetric multi-GPU path ----------------------------------------------------------------------------
+ * K_ff is symmetric, and the symmetric pair kernel (each kappa_ij used for out_i and out_j) halves the work of a mat-vec.
+ * To keep that factor under sharding the GLOBAL upper triangle is dealt to the ranks by cyclic 256-row blocks:
+ * cglb_matvec_cyclic produces this rank's full-length PARTIAL K_ff p (no noise term); the host all-reduces it and every
+ * rank holds the full vectors p, Ap, v, r (their updates are O(N) and done redundantly with the cglb_vec_* primitives).
+ * Only the Nystrom panel stays column-sharded (rows [row_begin,row_end)): u = A r is all-reduced (M), z is all-gathered. */
+int cglb_set_parallel(cglb_ctx* ctx, int world, int rank);
+int cglb_matvec_cyclic(cglb_ctx* ctx, const void* p_full, void* out_full_partial /* dev [n_total] */);
+int cglb_rhs_full(cglb_ctx* ctx, void* out_full /* dev [n_total] */); /* y - mean for all rows */
+/* vector primitives with an explicit length (same kernels as the cglb_shard_* ones) */
+int cglb_vec_dot(cglb_ctx* ctx, int64_t n, const void* a, const void* b, void* out /* dev double[1] */);
+int cglb_vec_update_v_r(cglb_ctx* ctx, int64_t n, void* v, void* r, const void* p, const void* Ap, const void* rz, const void* pAp, int update_r);
+int cglb_vec_residual(cglb_ctx* ctx, int64_t n, void* r, const void* b, const void* Kv);
+int cglb_vec_update_p(cglb_ctx* ctx, int64_t n, void* p, const void* z, const void* new_rz, const void* rz, int restart);
+int cglb_vec_axpy(cglb_ctx* ctx, int64_t n, double alpha, const void* x, void* y); /* y += alpha x */
+/* objective phase 1 with (K_ff + noise I) v already computed for the local rows; phase 2 unchanged; the local slice of
+ * w = P r for the all-gather of u = w + v/2; phase 3 with the cyclic share of the N^2 gradient form (u_full gathered). */
+int cglb_shard_obj_phase1_kv(cglb_ctx* ctx, const void* Kv_local, void* u_partial);
+int cglb_shard_obj_w(cglb_ctx* ctx, void* w_local_out);
+int cglb_shard_obj_phase3_cyclic(cglb_ctx* ctx, const void* v_full, const void* u_full, const void* sc, const void* aw, void* grad_partial);
+
 /* ---- prediction seam: PredictCG.forward, models.py:307-354 (needs common terms + a solved v) ------ */
 /* f_mean, f_var: dev [n_new].  v_full: dev [n] solution at tolerance 1e-3 (models.py:291). single shard. */
 int cglb_predict(cglb_ctx* ctx, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var);

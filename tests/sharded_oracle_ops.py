@@ -130,3 +130,82 @@ class OracleLocalOps(LocalOps):
         logdet = -float(np.log(np.diag(self.LB)).sum()) - 0.5 * N * math.log(h.noise) - 0.5 * N * math.log(tau)
         lower, upper = scn[0], scn[0] + 0.5 * scn[1]
         return -upper + logdet - 0.5 * N * math.log(2 * math.pi), lower, upper, logdet
+
+
+from cglb_amd.distributed import SymLocalOps
+
+
+class OracleSymLocalOps(OracleLocalOps, SymLocalOps):
+    """Oracle-backed local ops of the cyclic-symmetric driver.  The K_ff work is split exactly like the HIP kernels do it:
+    256-row blocks of the global upper triangle, block rb belongs to rank rb % world; a block contributes its rows against
+    all columns from its own first row on, and the transposed contribution to the columns right of the block."""
+
+    RB = 256
+    GB = 512  # row-block size of the gradient N^2 pass (256 threads x 2 rows)
+
+    def __init__(self, kind, X, y, hyp, r0, r1):
+        super().__init__(kind, X, y, hyp, r0, r1)
+        self.world, self.rank = 1, 0
+        self.Kfull = orc.kernel_matrix(kind, X, X, hyp.lengthscales, hyp.variance)
+
+    @property
+    def noise(self):
+        return self.hyp.noise
+
+    def set_parallel(self, world, rank):
+        self.world, self.rank = world, rank
+
+    def rhs_full(self, out): out.copy_(torch.from_numpy(self.y - self.hyp.mean))
+
+    def matvec_cyclic(self, p_full, out):
+        p = p_full.numpy()
+        res = np.zeros(self.N)
+        nrb = (self.N + self.RB - 1) // self.RB
+        for rb in range(self.rank, nrb, self.world):
+            a, b = rb * self.RB, min((rb + 1) * self.RB, self.N)
+            res[a:b] += self.Kfull[a:b, a:] @ p[a:]          # rows of the block against columns >= its first row
+            if b < self.N:
+                res[b:] += self.Kfull[a:b, b:].T @ p[a:b]    # transposed use of the strictly-right part
+        out.copy_(torch.from_numpy(res))
+
+    def vec_dot(self, n, a, b, out): out[0] = float(a.numpy()[:n] @ b.numpy()[:n])
+    def vec_update_v_r(self, n, v, r, p, Ap, rz, pAp, update_r): self.update_v_r(v[:n], r[:n], p[:n], Ap[:n], rz, pAp, update_r)
+    def vec_residual(self, n, r, b, Kv): r[:n].copy_(b[:n] - Kv[:n])
+    def vec_update_p(self, n, p, z, new_rz, rz, restart): self.update_p(p[:n], z[:n], new_rz, rz, restart)
+    def vec_axpy(self, n, alpha, x, y): y[:n] += alpha * x[:n]
+
+    def obj_phase1_kv(self, Kv_local, u):
+        self.e = self.y[self.r0:self.r1] - self.hyp.mean
+        self.Kv = Kv_local.numpy().copy()
+        self.res = self.e - self.Kv
+        u.copy_(torch.from_numpy(self.A @ self.res))
+
+    def obj_w(self, out): out.copy_(torch.from_numpy(self.w))
+
+    def obj_phase3_cyclic(self, v_full, u_full, sc, aw, grad):
+        # everything except the N^2 form exactly as the row-sharded phase 3 ...
+        saved = self.Kloc
+        super().obj_phase3(v_full, sc, aw, grad)
+        g = grad.numpy().copy()
+        D, ls, f = self.D, np.asarray(self.hyp.lengthscales, dtype=np.float64), self.hyp.variance
+        v, u = v_full.numpy(), u_full.numpy()
+        Xs = self.X / ls
+        # ... minus the row-sharded N^2 part it added, plus this rank's cyclic share of the symmetric form
+        if self.r1 > self.r0:
+            Xl = self.X[self.r0:self.r1]
+            uu = self.w + 0.5 * v[self.r0:self.r1]
+            Wff = orc.kernel_grad_factor(self.kind, orc.scaled_sqdist(Xl, self.X, ls), f) * np.outer(uu, v)
+            for d in range(D):
+                dl = Xl[:, d][:, None] / ls[d] - Xs[:, d][None, :]
+                g[d] -= (Wff * dl * dl).sum() / ls[d]
+        nb = (self.N + self.GB - 1) // self.GB
+        for rb in range(self.rank, nb, self.world):
+            a, b = rb * self.GB, min((rb + 1) * self.GB, self.N)
+            h = orc.kernel_grad_factor(self.kind, orc.scaled_sqdist(self.X[a:b], self.X[a:], ls), f)
+            W = h * np.outer(u[a:b], v[a:])
+            if b < self.N:
+                W[:, b - a:] += h[:, b - a:] * np.outer(v[a:b], u[b:])
+            for d in range(D):
+                dl = Xs[a:b, d][:, None] - Xs[a:, d][None, :]
+                g[d] += (W * dl * dl).sum() / ls[d]
+        grad.copy_(torch.from_numpy(g))

@@ -81,3 +81,49 @@ def test_row_partition_covers_all_rows():
         assert parts[0][0] == 0 and parts[-1][1] == n and len(parts) == w
         assert all(a1 == b0 for (_, a1), (b0, _) in zip(parts[:-1], parts[1:]))
         assert all(0 <= b - a <= per for a, b in parts)
+
+
+def _worker_sym(rank, world, port, name, max_error, max_iter, restart, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cglb_amd.distributed import Comm, SymShardedCGLB, row_partition
+        from sharded_oracle_ops import OracleSymLocalOps
+        g = load_golden(name)
+        hyp = golden_hypers(g)
+        per, parts = row_partition(g["X"].shape[0], world)
+        ops = OracleSymLocalOps(int(g["kind"]), g["X"], g["y"], hyp, *parts[rank])
+        drv = SymShardedCGLB(ops, Comm())
+        drv.v.copy_(torch.from_numpy(g["v0"]))
+        res = drv.objective_and_grad(True, max_error, max_iter, restart)
+        if rank == world - 1:   # any rank holds the full result; take the last one to check replication
+            q.put((res.bound, res.lower, res.upper, res.steps, res.residual_error, res.grad, drv.v_full().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("rbf_d8_trained", 2), ("m32_d3_random", 3), ("rbf_d8_restart", 2), ("c1_snelson_like_m32", 2)])
+def test_cyclic_symmetric_driver_matches_single_process(name, world):
+    g = load_golden(name)
+    hyp = golden_hypers(g)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    args = (world, port, name, float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]), q)
+    procs = [ctx.Process(target=_worker_sym, args=(r,) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    bound, lower, upper, steps, half_rz, grad, v_full = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = orc.objective(int(g["kind"]), g["X"], g["y"], hyp, g["v0"], True, float(g["max_error"]), int(g["max_cg_iter"]),
+                        int(g["restart_cg_iter"]))
+    assert abs(steps - ref.steps) <= (0 if ref.steps <= 40 else 1)
+    assert bound == pytest.approx(ref.bound, rel=1e-8)
+    assert bound == pytest.approx(float(g["bound"]), rel=1e-6)
+    refg = orc.objective(int(g["kind"]), g["X"], g["y"], hyp, v_full, run_cg=False, with_grad=True)
+    assert bound == pytest.approx(refg.bound, rel=1e-12)
+    packed = np.concatenate([refg.grad["lengthscales"], [refg.grad["variance"], refg.grad["noise"], refg.grad["mean"]], refg.grad["Z"].reshape(-1)])
+    np.testing.assert_allclose(grad, packed, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(packed).max()))

@@ -63,3 +63,26 @@ def test_matvec_row_shard_and_linearity(variant):
     # run-twice determinism (fixed-order combine, no atomics)
     again = full.matvec(torch.from_numpy(p)).cpu().numpy()
     assert np.array_equal(again, ref)
+
+
+@pytest.mark.parametrize("N,world", [(2999, 2), (2999, 3), (5000, 8), (300, 4)])
+def test_cyclic_partials_sum_to_full_matvec(N, world):
+    """cglb_matvec_cyclic: the per-rank partial vectors of the cyclic-symmetric split add up to K_ff p (all ranks emulated
+    in one process, no collectives)."""
+    from ctypes import c_void_p
+    from cglb_amd import _lib
+    from cglb_amd.hip_context import HipContext
+    X, y, Z = orc.synthetic_problem(N, 8, 8, seed=N)
+    h = orc.trained_like_hypers(8, Z)
+    rng = np.random.default_rng(3)
+    p = torch.from_numpy(rng.standard_normal(N)).cuda()
+    ctx = HipContext(X, y, 8, "rbf")
+    ctx.set_hypers(h.lengthscales, h.variance, h.noise, h.mean, Z, 1e-6)
+    ref = ctx.matvec(p).cpu().numpy() - h.noise * p.cpu().numpy()
+    total = np.zeros(N)
+    for rank in range(world):
+        _lib.check(ctx.lib.cglb_set_parallel(ctx._ctx, world, rank), ctx._ctx)
+        out = torch.empty(N, dtype=torch.float64, device=ctx.device)
+        _lib.check(ctx.lib.cglb_matvec_cyclic(ctx._ctx, c_void_p(p.data_ptr()), c_void_p(out.data_ptr())), ctx._ctx)
+        total += out.cpu().numpy()
+    np.testing.assert_allclose(total, ref, rtol=0, atol=1e-12 * np.abs(ref).max())

@@ -93,3 +93,96 @@ def test_two_ranks_on_one_gpu_over_gloo(name):
     assert grad[D] == pytest.approx(fused.grad["variance"], rel=1e-8, abs=1e-9)
     assert grad[D + 1] == pytest.approx(fused.grad["noise"], rel=1e-8, abs=1e-9)
     np.testing.assert_allclose(grad[D + 3:], fused.grad["Z"].reshape(-1), rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["rbf_d8_trained", "m32_d3_random", "rbf_d8_restart"])
+def test_world1_cyclic_driver_equals_fused_path(name):
+    from cglb_amd.distributed import HipSymLocalOps, SymShardedCGLB
+    g = load_golden(name)
+    args = (float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+    ctx = _mk(g)
+    v = torch.from_numpy(g["v0"]).to(ctx.device).clone()
+    fused = ctx.objective_and_grad(v, True, *args)
+    ctx2 = _mk(g)
+    drv = SymShardedCGLB(HipSymLocalOps(ctx2))
+    drv.v.copy_(torch.from_numpy(g["v0"]).to(ctx2.device))
+    res = drv.objective_and_grad(True, *args)
+    assert res.steps == fused.steps
+    if fused.steps > 40:
+        # long solve: the two drivers sum r^T z in different orders and CG amplifies that round-off (see test_oracle_golden)
+        assert res.bound == pytest.approx(fused.bound, rel=1e-8)
+        return
+    assert res.bound == pytest.approx(fused.bound, rel=1e-11)
+    D = g["X"].shape[1]
+    np.testing.assert_allclose(res.grad[:D], fused.grad["lengthscales"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(res.grad[D + 3:], fused.grad["Z"].reshape(-1), rtol=1e-8, atol=1e-10)
+
+
+def _worker_sym(rank, world, port, name, N, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cglb_amd.distributed import Comm, HipSymLocalOps, SymShardedCGLB, row_partition
+        from cglb_amd.hip_context import HipContext
+        from oracle import cglb_oracle as orc
+        torch.cuda.set_device(0)
+        if name:
+            g = load_golden(name)
+            X, y, hyp, kind, v0 = g["X"], g["y"], golden_hypers(g), int(g["kind"]), g["v0"]
+            cg = (float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+        else:  # larger ragged problem: several 256-row blocks per rank, N not a multiple of anything.  Well-conditioned
+            # hypers (noise 1): a short solve, so that drivers that sum in different orders agree to round-off
+            X, y, Z = orc.synthetic_problem(N, 8, 32, seed=7)
+            hyp = orc.reference_init_hypers(8, Z)
+            hyp.lengthscales = np.full(8, 1.5)
+            kind, v0, cg = 0, np.zeros(N), (1e-3, 100, 40)
+        per, parts = row_partition(X.shape[0], world)
+        ctx = HipContext(X, y, hyp.Z.shape[0], kind, row_range=parts[rank])
+        ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, hyp.Z, hyp.jitter)
+        drv = SymShardedCGLB(HipSymLocalOps(ctx), Comm())
+        drv.v.copy_(torch.from_numpy(v0).to(ctx.device))
+        res = drv.objective_and_grad(True, *cg)
+        if rank == world - 1:
+            q.put((res.bound, res.steps, res.grad))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,N,world", [("rbf_d8_trained", 0, 2), ("m32_d3_random", 0, 3), ("", 2999, 2)])
+def test_cyclic_symmetric_ranks_on_one_gpu_over_gloo(name, N, world):
+    from oracle import cglb_oracle as orc
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker_sym, args=(r, world, port, name, N, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    bound, steps, grad = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    if name:
+        g = load_golden(name)
+        X, y, hyp, kind, v0 = g["X"], g["y"], golden_hypers(g), int(g["kind"]), g["v0"]
+        cg = (float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+        assert steps == int(g["steps"])
+        assert bound == pytest.approx(float(g["bound"]), rel=1e-9)
+    else:
+        X, y, Z = orc.synthetic_problem(N, 8, 32, seed=7)
+        hyp = orc.reference_init_hypers(8, Z)
+        hyp.lengthscales = np.full(8, 1.5)
+        kind, v0, cg = 0, np.zeros(N), (1e-3, 100, 40)
+    from cglb_amd.hip_context import HipContext
+    ctx = HipContext(X, y, hyp.Z.shape[0], kind)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, hyp.Z, hyp.jitter)
+    v = torch.from_numpy(v0).to(ctx.device).clone()
+    fused = ctx.objective_and_grad(v, True, *cg)
+    assert steps == fused.steps and steps <= 40
+    assert bound == pytest.approx(fused.bound, rel=1e-10)
+    D = X.shape[1]
+    np.testing.assert_allclose(grad[:D], fused.grad["lengthscales"], rtol=1e-8, atol=1e-9)
+    assert grad[D] == pytest.approx(fused.grad["variance"], rel=1e-8, abs=1e-9)
+    assert grad[D + 1] == pytest.approx(fused.grad["noise"], rel=1e-8, abs=1e-9)
+    np.testing.assert_allclose(grad[D + 3:], fused.grad["Z"].reshape(-1), rtol=1e-8, atol=1e-9)
