@@ -84,9 +84,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100_000)
-    ap.add_argument("--d", type=int, default=8)
-    ap.add_argument("--m", type=int, default=1024)
+    ap.add_argument("--rows", type=int, default=100_000, help="N (training rows)")
+    ap.add_argument("--dims", type=int, default=8, help="D (input dimension)")
+    ap.add_argument("--inducing", type=int, default=1024, help="M (inducing points)")
     ap.add_argument("--kernel", default="rbf", choices=["rbf", "matern32"])
     ap.add_argument("--hypers", default="trained", choices=["trained", "init"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,14 +104,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the product path has no CPU fallback")
+    # Rehearsal knobs for a one-GPU box only (the real multi-GPU run uses neither): CGLB_BENCH_BACKEND=gloo and
+    # CGLB_BENCH_SHARE_GPU=1 let several ranks share cuda:0 so that the N > 1 code path can be exercised end to end.
+    backend = os.environ.get("CGLB_BENCH_BACKEND", "nccl")
+    if os.environ.get("CGLB_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
-    N, D, M, kind = args.n, args.d, args.m, args.kernel
+    N, D, M, kind = args.rows, args.dims, args.inducing, args.kernel
     X, y, Z = synthetic_problem(N, D, M, seed=0)
     hypers = {"trained": trained_like_hypers(D), "init": reference_init_hypers(D)}
     cg = dict(max_error=1.0, max_cg_iter=100, restart_cg_iter=40)  # conjugate_gradient.py:37-39
@@ -172,12 +180,12 @@ def main():
         comm.allreduce(ctx.aat_tensor())
     ctx.setup_finish()
     reps = 10
-    ms_pair = ctx.time_kernel(3, reps)   # kff_matvec_kernel alone
+    ms_pair = ctx.time_kernel(3 if world == 1 else 4, reps)   # pair kernel alone (N > 1: this rank's cyclic share of the triangle)
     ms_prec = ctx.time_kernel(1, reps)   # preconditioner apply (gemv_u + triangular products + gemv_t + epilogue)
     nloc = parts[rank][1] - parts[rank][0]
-    # algorithmic pairs of one launch of the dominant kernel on this rank: all of K_ff on one GPU; with N > 1 the kernel timed
-    # here is the row-shard form (rows of this rank x all columns) that the C ABI's cglb_matvec exposes
-    flops = pair_flops(kind, D) * float(N) * float(nloc)
+    # algorithmic pairs of one launch of the dominant kernel on this rank: all N^2 of K_ff on one GPU, N^2 / world with the
+    # cyclic-symmetric split
+    flops = pair_flops(kind, D) * float(N) * float(N) / world
     achieved = flops / (ms_pair * 1e-3) / 1e12
     esz = 8
     prec_bytes = 2.0 * M * nloc * esz + 3.0 * nloc * esz

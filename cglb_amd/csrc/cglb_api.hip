@@ -822,7 +822,7 @@ int cglb_get_matrix(cglb_ctx* c, int which, void* dst) {
 int cglb_time_kernel(cglb_ctx* c, int which, int reps, double* ms_avg) {
     if (!c || !ms_avg || reps <= 0) return CGLB_ERR_BAD_ARG;
     if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede timing");
-    if (which != 0 && which != 3) CGLB_TRY(require_terms(c));
+    if (which != 0 && which != 3 && which != 4) CGLB_TRY(require_terms(c));
     HIP_CHECK(c, hipSetDevice(c->device));
     // operands: y as a generic vector (values do not change the instruction stream)
     hipEvent_t e0, e1;
@@ -833,6 +833,12 @@ int cglb_time_kernel(cglb_ctx* c, int which, int reps, double* ms_avg) {
         if (which == 0) return launch_kff_matvec(c, c->y, c->w_Ap, nullptr);
         if (which == 1) return precond_single(c, (const char*)c->y + (size_t)c->r0 * c->esz, c->w_z, c->scal + S_TMP);
         if (which == 2) return launch_grad_kff(c, c->y, (const char*)c->y + (size_t)c->r0 * c->esz, c->scal + S_TMP2);
+        if (which == 4) {  // this rank's cyclic share of the global symmetric mat-vec (pair kernel alone), multi-GPU path
+            c->kff_skip_combine = true;
+            const int r = launch_kff_sym_cyclic(c, c->y, c->w_pfull);
+            c->kff_skip_combine = false;
+            return r;
+        }
         if (which == 3) {  // the pair kernel of the mat-vec alone (what rocprofv3 lists as kff_matvec_kernel)
             c->kff_skip_combine = true;
             const int r = launch_kff_matvec(c, c->y, c->w_Ap, nullptr);

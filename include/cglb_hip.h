@@ -161,7 +161,7 @@ int cglb_predict(cglb_ctx* ctx, const void* v_full, const void* xnew, int64_t n_
 int cglb_get_matrix(cglb_ctx* ctx, int which, void* dst);
 /* Average duration (ms, HIP events on the ctx stream) of `reps` back-to-back launches of one kernel family:
  * which = 0: K_ff mat-vec (pair kernel + slab combine), 1: preconditioner apply, 2: gradient bilinear pass,
- * 3: the pair kernel of the mat-vec alone (the dominant kernel). */
+ * 3: the pair kernel of the mat-vec alone (the dominant kernel), 4: the same for this rank's cyclic share (cglb_set_parallel). */
 int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
 /* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" ...; returns CGLB_ERR_BAD_ARG if unknown. */
 int cglb_set_option(cglb_ctx* ctx, const char* name, int64_t value);
