@@ -165,3 +165,24 @@ def test_solver_and_preconditioner_seams():
     assert float(v0.abs().max()) == 0.0 and vout.shape == v0.shape and isinstance(stats.steps, int)
     with pytest.raises(TypeError):
         ConjugateGradient()(torch.eye(hip.N, dtype=torch.float64), b, v0, NystromPreconditioner(hip))
+
+
+def test_cli_train_and_metric_roundtrip(tmp_path):
+    """Config C1 plumbing (snelson-like, Matern32, M=16, fp64) through the click command tree of cli.py:60-152."""
+    from click.testing import CliRunner
+    from cglb_amd.cli import main
+    logdir = str(tmp_path / "run")
+    r = CliRunner().invoke(main, ["-b", "hip", "-t", "fp64", "-l", logdir, "-s", "0", "train", "-d", "snelson-like", "-n", "15",
+                                  "cglb", "-k", "Matern32", "-m", "cglb", "-i", "cv", "-M", "16"], catch_exceptions=False)
+    assert r.exit_code == 0, r.output
+    for f in ("model.json", "results.json", "logs.json"):
+        assert os.path.exists(os.path.join(logdir, f))
+    results = json.load(open(os.path.join(logdir, "results.json")))
+    logs = json.load(open(os.path.join(logdir, "logs.json")))
+    assert {"loss", "train/rmse", "test/rmse", "train/nlpd", "test/nlpd", "cg/steps", "cg/error", "id"} <= set(results)
+    assert {"loss", "elapsed_time", "params", "steps-per-feval", "residual_error-per-feval", "id"} <= set(logs)
+    assert results["test/rmse"] < 0.6
+    r2 = CliRunner().invoke(main, ["-b", "hip", "-t", "fp64", "-l", logdir, "metric", "-d", "snelson-like", "cglb", "-k", "Matern32",
+                                   "-m", "cglb", "-i", "cv", "-M", "16", "-p", os.path.join(logdir, "model.json")], catch_exceptions=False)
+    assert r2.exit_code == 0, r2.output
+    assert os.path.exists(os.path.join(logdir, "metric.npy"))
