@@ -55,17 +55,14 @@ template <bool CLAMP> __device__ __forceinline__ double exp2_hot(double x) {
 }
 template <bool CLAMP> __device__ __forceinline__ float exp2_hot(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// sqrt for x >= 0: hardware rsq seed (~2^-23 on fp64) + two coupled Goldschmidt steps + one residual
-// correction -> <= 1 ulp.  x == 0 returns 0.
+// sqrt for x >= 0: hardware rsq seed (relative error e0 <= ~2^-23 on fp64), one coupled Goldschmidt step (-> ~e0^2) and one
+// residual correction (-> ~e0^4, i.e. correctly rounded up to the last fma).  x == 0 returns 0.  8 instructions.
 __device__ __forceinline__ double sqrt_pos(double x) {
     const double xs = fmax(x, 1e-280);
-    double y = __builtin_amdgcn_rsq(xs);
+    const double y = __builtin_amdgcn_rsq(xs);
     double g = xs * y;
     double h = 0.5 * y;
-    double e = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, e, g);
-    h = __builtin_fma(h, e, h);
-    e = __builtin_fma(-h, g, 0.5);
+    const double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
     h = __builtin_fma(h, e, h);
     const double d = __builtin_fma(-g, g, xs);
@@ -73,6 +70,21 @@ __device__ __forceinline__ double sqrt_pos(double x) {
     return x > 0.0 ? g : 0.0;
 }
 __device__ __forceinline__ float sqrt_pos(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
+
+// Hot-loop variant for a squared distance that may come out slightly negative (Gram form): the clamp to a tiny positive
+// number replaces both the max(.,0) and the x > 0 select; sqrt_hot(d2 <= 0) = 1e-140, which the Matern profile maps to 1.
+__device__ __forceinline__ double sqrt_hot(double x) {
+    const double xs = fmax(x, 1e-280);
+    const double y = __builtin_amdgcn_rsq(xs);
+    double g = xs * y;
+    double h = 0.5 * y;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    const double d = __builtin_fma(-g, g, xs);
+    return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ float sqrt_hot(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
 
 // Table-driven 2^(x/64): the hot pair kernels keep their operands in units of 1/64 octave (x64 = 64*log2 of the value), so
 //   x64 = n + s, |s| <= 1/2;  2^(x64/64) = 2^(n>>6) * TAB[n & 63] * P5(s),  TAB[k] = 2^(k/64) (correctly rounded, in LDS),
@@ -132,7 +144,7 @@ __device__ __forceinline__ T kappa_hot_from_gram(T gram, T aj, const double* __r
         return exp2_tab<CLAMP>(gram + aj, tab);
     } else {
         T d2 = tfma<T>(T(-2), gram, aj);
-        T r = sqrt_pos(tmax<T>(d2, T(0)));
+        T r = sqrt_hot(d2);
         return tfma<T>(r, T(CGLB_LN2 / CGLB_HOT_UNITS), T(1)) * exp2_tab<CLAMP>(-r, tab);
     }
 }
@@ -148,7 +160,7 @@ __device__ __forceinline__ KappaPend<T> kappa_hot_begin(T gram, T aj, const doub
         k.lin = T(1);
     } else {
         const T d2 = tfma<T>(T(-2), gram, aj);
-        const T r = sqrt_pos(tmax<T>(d2, T(0)));
+        const T r = sqrt_hot(d2);
         k.lin = tfma<T>(r, T(CGLB_LN2 / CGLB_HOT_UNITS), T(1));
         x64 = -r;
     }
