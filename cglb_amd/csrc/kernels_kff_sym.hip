@@ -183,14 +183,30 @@ __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restric
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double contrib = 0.0;
     if (i < n) {
-        T s = 0;
-        for (int q = 0; q < nplain; ++q) s += plain[(int64_t)q * n + i];
+        // slot sums with 8 independent accumulators: the slab rows are n elements apart, so a single running sum would
+        // serialise ~300 dependent loads per element; the order is still fixed (bitwise reproducible)
+        T a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < nplain; ++q) a[q & 7] += plain[(int64_t)q * n + i];
         const int64_t rbi = i / rbrows;
         if (rbi % world == rank) {
             const int64_t k0 = (rbi * rbrows) / chunk;
-            for (int64_t k = k0; k < nchunk; ++k) s += Prow[k * n + i];
+            int64_t k = k0;
+            for (; k + 8 <= nchunk; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] += Prow[(k + u) * n + i];
+            }
+            for (int u = 0; k < nchunk; ++k, ++u) a[u] += Prow[k * n + i];
         }
-        for (int64_t rb = rank; rb < rbi; rb += world) s += Pcol[(rb / world) * n + i];
+        {
+            const int64_t ns = rbi > rank ? (rbi - rank + world - 1) / world : 0;  // column-sum slots 0 .. ns-1 are valid for this element
+            int64_t c = 0;
+            for (; c + 8 <= ns; c += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] += Pcol[(c + u) * n + i];
+            }
+            for (int u = 0; c < ns; ++c, ++u) a[u] += Pcol[c * n + i];
+        }
+        const T s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         T o = var * s;
         if (pdiag) {
             o = tfma<T>(noise, pdiag[i], o);
