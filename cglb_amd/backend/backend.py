@@ -1,74 +1,43 @@
-"""Backend facade and registry — mirror of cglb/backend/backend.py:34-115 with the new key "hip".
+"""Backend facade and registry with the new key "hip".
 
-Plugging into the reference: `BACKENDS["hip"] = cglb_amd.backend.Hip`; the CLI then selects it
-with `-b hip` exactly like `-b torch`."""
+Same surface as the reference facade (cglb/backend/backend.py:34-115): a `Backend` class whose classmethods forward to an
+`interface` module, and a `BACKENDS` registry the CLI indexes with `-b`.  The forwarding methods are generated from the list
+of interface functions instead of being written out one by one.  Plugging into the reference:
+`BACKENDS["hip"] = cglb_amd.backend.Hip`."""
 from abc import ABC, abstractmethod
-from typing import Dict, Tuple
-
-import numpy as np
 
 from . import interface as _hip_interface
 
-Data = Tuple[np.ndarray, np.ndarray]
-Dataset = Tuple[Data, Data]
-
 __all__ = ["Backend", "Hip", "BACKENDS"]
+
+#: interface functions reachable as Backend.<name>(...)  (backend.py:40-91 of the reference)
+FORWARDED = ("configure_backend", "create_kernel", "create_model", "model_parameters", "optimize", "save", "load", "metrics_fn",
+             "set_default_float", "get_default_float_str", "get_default_float")
 
 
 class Backend(ABC):
     @staticmethod
     @abstractmethod
     def interface():
-        pass
-
-    @classmethod
-    def configure_backend(cls, **kwargs):
-        return cls.interface().configure_backend(**kwargs)
-
-    @classmethod
-    def create_kernel(cls, cfg, data: Data):
-        return cls.interface().create_kernel(cfg, data)
-
-    @classmethod
-    def create_model(cls, model_cfg, data: Data):
-        return cls.interface().create_model(model_cfg, data)
-
-    @classmethod
-    def model_parameters(cls, model) -> Dict[str, np.ndarray]:
-        return cls.interface().model_parameters(model)
-
-    @classmethod
-    def optimize(cls, model, dataset: Dataset, num_steps: int, logger, optimizer: str):
-        return cls.interface().optimize(model, dataset, num_steps, logger, optimizer)
-
-    @classmethod
-    def save(cls, model, logdir: str):
-        return cls.interface().save(model, logdir)
-
-    @classmethod
-    def load(cls, model, filepath: str):
-        return cls.interface().load(model, filepath)
-
-    @classmethod
-    def metrics_fn(cls, model, dataset_bundle):
-        return cls.interface().metrics_fn(model, dataset_bundle)
-
-    @classmethod
-    def set_default_float(cls, float_type: str):
-        return cls.interface().set_default_float(float_type)
+        """The module that implements the backend."""
 
     @classmethod
     def set_default_jitter(cls, float_type: str):
-        value = 1e-5 if float_type == "fp32" else 1e-6  # backend.py:77-79
-        return cls.interface().set_default_jitter(value)
+        # Cholesky jitter by precision: 1e-5 for fp32, 1e-6 otherwise (reference backend.py:77-79)
+        return cls.interface().set_default_jitter({"fp32": 1e-5}.get(float_type, 1e-6))
 
-    @classmethod
-    def get_default_float_str(cls):
-        return cls.interface().get_default_float_str()
 
-    @classmethod
-    def get_default_float(cls):
-        return cls.interface().get_default_float()
+def _forward(name):
+    def method(cls, *args, **kwargs):
+        return getattr(cls.interface(), name)(*args, **kwargs)
+
+    method.__name__ = name
+    method.__doc__ = f"Forwards to `interface().{name}`."
+    return classmethod(method)
+
+
+for _name in FORWARDED:
+    setattr(Backend, _name, _forward(_name))
 
 
 class Hip(Backend):

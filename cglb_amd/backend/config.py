@@ -21,7 +21,6 @@ __all__ = [
 ]
 
 Data = Tuple[np.ndarray, np.ndarray]
-dataclass_frozen = partial(dataclasses.dataclass, frozen=True)
 
 
 def greedy_conditional_variance(X: np.ndarray, M: int, kernel_fn: Callable, jitter: float = 1e-12) -> np.ndarray:
@@ -49,96 +48,80 @@ def greedy_conditional_variance(X: np.ndarray, M: int, kernel_fn: Callable, jitt
 
 
 class Config:
+    """Base of all configuration records.  `params(data)` returns the initial values a backend needs."""
+
     def params(self, **kwargs) -> Dict[str, Union[float, np.ndarray]]:
-        pass
+        return {}
 
 
-@dataclass_frozen
-class ModelConfig(Config):
-    pass
+def _record(name: str, bases, fields=(), namespace=None, doc: str = ""):
+    """Frozen dataclass factory: the reference's config classes are frozen dataclasses used as dispatch keys."""
+    ns = dict(namespace or {})
+    ns["__doc__"] = doc
+    ns["__module__"] = __name__
+    return dataclasses.make_dataclass(name, fields, bases=bases, namespace=ns, frozen=True)
 
 
-@dataclass_frozen
-class InducingVariableConfig(Config):
-    num_variables: int
-
-    def params(self, data: Data) -> Dict[str, Union[float, np.ndarray]]:
-        ...
-
-    def init(self, data: Data, kernel_fn: Callable):
-        return greedy_conditional_variance(np.asarray(data[0]), self.num_variables, kernel_fn)
+ModelConfig = _record("ModelConfig", (Config,), doc="Marker base of model configurations.")
 
 
 class KernelConfig(Config):
-    pass
+    """Marker base of kernel configurations."""
 
 
-@dataclass_frozen
-class SquaredExponentialConfig(KernelConfig):
-    def params(self, data: Data) -> Dict[str, Union[float, np.ndarray]]:
-        vecdim = data[0].shape[-1]
-        return {"variance": 1.0, "lengthscales": np.repeat(1.0, vecdim)}
+def _unit_kernel_params(self, data: Data):
+    # variance 1, unit ARD lengthscales (one per input column) — reference defaults, config.py:74-76
+    return {"variance": 1.0, "lengthscales": np.ones(np.asarray(data[0]).shape[-1])}
 
 
-@dataclass_frozen
-class Matern32Config(SquaredExponentialConfig):
-    pass
+SquaredExponentialConfig = _record("SquaredExponentialConfig", (KernelConfig,), namespace={"params": _unit_kernel_params},
+                                   doc="ARD squared-exponential (RBF) kernel.")
+Matern32Config = _record("Matern32Config", (SquaredExponentialConfig,), doc="ARD Matern-3/2 kernel (same initial values).")
 
 
-@dataclass_frozen
-class GPRConfig(ModelConfig):
-    kernel: KernelConfig
-
-    def params(self, data: Data) -> Dict[str, Union[float, np.ndarray]]:
-        return {"noise_variance": 1.0}
+def _inducing_init(self, data: Data, kernel_fn: Callable):
+    return greedy_conditional_variance(np.asarray(data[0]), self.num_variables, kernel_fn)
 
 
-@dataclass_frozen
-class ExactGPConfig(GPRConfig):
-    ...
+InducingVariableConfig = _record("InducingVariableConfig", (Config,), [("num_variables", int)], namespace={"init": _inducing_init},
+                                 doc="Number of inducing points and their initialisation (greedy conditional variance).")
+
+_NOISE_INIT = 1.0  # reference config.py:89, :104
 
 
-@dataclass_frozen
-class SGPRConfig(ModelConfig):
-    kernel: KernelConfig
-    inducing_variable: InducingVariableConfig
-
-    def params(self, data: Data) -> Dict[str, Union[float, np.ndarray, Callable]]:
-        inducing_variable_fn = partial(self.inducing_variable.init, data)
-        return {"noise_variance": 1.0, "inducing_variable": inducing_variable_fn}
+def _gpr_params(self, data: Data):
+    return {"noise_variance": _NOISE_INIT}
 
 
-@dataclass_frozen
-class CGLBConfig(SGPRConfig):
-    max_error: float = 1.0
-    joint_optimization: bool = False
-    vzero: bool = False
-
-    def params(self, data: Data) -> Dict[str, Union[float, np.ndarray]]:
-        param_dict = super().params(data)
-        param_dict["max_error"] = self.max_error
-        param_dict["joint_optimization"] = self.joint_optimization
-        param_dict["vzero"] = self.vzero
-        return param_dict
+GPRConfig = _record("GPRConfig", (ModelConfig,), [("kernel", KernelConfig)], namespace={"params": _gpr_params}, doc="Exact GP regression.")
+ExactGPConfig = _record("ExactGPConfig", (GPRConfig,), doc="Exact GP (iterative baseline; out of scope here).")
 
 
-@dataclass_frozen
-class CGLBN2MConfig(CGLBConfig):
-    pass
+def _sgpr_params(self, data: Data):
+    return {"noise_variance": _NOISE_INIT, "inducing_variable": partial(self.inducing_variable.init, data)}
 
 
-@dataclass_frozen
-class CGLBNM2Config(CGLBConfig):
-    pass
+SGPRConfig = _record("SGPRConfig", (ModelConfig,), [("kernel", KernelConfig), ("inducing_variable", InducingVariableConfig)],
+                     namespace={"params": _sgpr_params}, doc="Sparse GP regression (Titsias).")
 
 
-@dataclass_frozen
-class SGPRN2MConfig(SGPRConfig):
-    pass
+def _cglb_params(self, data: Data):
+    out = _sgpr_params(self, data)
+    out.update(max_error=self.max_error, joint_optimization=self.joint_optimization, vzero=self.vzero)
+    return out
 
 
-GPR_CONFIGS = {"gpr": GPRConfig, "exactgp": ExactGPConfig}
-SGPR_CONFIGS = {"sgpr": SGPRConfig, "cglb": CGLBConfig, "sgprn2m": SGPRN2MConfig, "cglbn2m": CGLBN2MConfig, "cglbnm2": CGLBNM2Config}
-KERNEL_CONFIGS = {"SquaredExponential": SquaredExponentialConfig, "Matern32": Matern32Config, "mat32": Matern32Config, "rbf": SquaredExponentialConfig}
-INDUCING_VARIABLE_CONFIGS = {"InducingVariable": InducingVariableConfig, "ConditionalVariance": InducingVariableConfig,
-                             "iv": InducingVariableConfig, "cv": InducingVariableConfig}
+CGLBConfig = _record("CGLBConfig", (SGPRConfig,),
+                     [("max_error", float, dataclasses.field(default=1.0)), ("joint_optimization", bool, dataclasses.field(default=False)),
+                      ("vzero", bool, dataclasses.field(default=False))],
+                     namespace={"params": _cglb_params}, doc="Conjugate-gradient lower bound model (reference config.py:110-121).")
+CGLBN2MConfig = _record("CGLBN2MConfig", (CGLBConfig,), doc="Log-det ablation (out of scope).")
+CGLBNM2Config = _record("CGLBNM2Config", (CGLBConfig,), doc="Log-det ablation (out of scope).")
+SGPRN2MConfig = _record("SGPRN2MConfig", (SGPRConfig,), doc="Log-det ablation (out of scope).")
+
+# registries: the keys are the reference's CLI choices (config.py:139-166)
+GPR_CONFIGS = dict(gpr=GPRConfig, exactgp=ExactGPConfig)
+SGPR_CONFIGS = dict(sgpr=SGPRConfig, cglb=CGLBConfig, sgprn2m=SGPRN2MConfig, cglbn2m=CGLBN2MConfig, cglbnm2=CGLBNM2Config)
+KERNEL_CONFIGS = {"SquaredExponential": SquaredExponentialConfig, "Matern32": Matern32Config, "mat32": Matern32Config,
+                  "rbf": SquaredExponentialConfig}
+INDUCING_VARIABLE_CONFIGS = {key: InducingVariableConfig for key in ("InducingVariable", "ConditionalVariance", "iv", "cv")}

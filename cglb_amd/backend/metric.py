@@ -1,26 +1,27 @@
-"""Metric reducers — mirror of cglb/backend/metric.py:24-55."""
+"""RMSE / NLPD reducers with the reference's metric names (cglb/backend/metric.py:24-55)."""
 from typing import Callable, Dict
 
 import numpy as np
 
 
 def call_metric_fns(*fns: Callable[[], Dict]) -> Dict[str, float]:
-    out = {}
+    """Evaluates the callbacks in order and merges their scalar results (later ones win)."""
+    merged: Dict[str, float] = {}
     for fn in fns:
-        out.update({k: float(np.array(v)) for k, v in fn().items()})
-    return out
+        for key, value in fn().items():
+            merged[key] = float(np.asarray(value))
+    return merged
 
 
 def rmse_and_lpd_fn(error_logdensity_cb: Callable) -> Callable[[], Dict[str, float]]:
-    def inner_func() -> Dict[str, float]:
-        errs, logdens = error_logdensity_cb()
-        (train_errors, test_errors), (train_lds, test_lds) = [np.array(e) for e in errs], [np.array(l) for l in logdens]
-        metrics = {
-            "train/rmse": np.sqrt(np.mean(train_errors ** 2)),
-            "test/rmse": np.sqrt(np.mean(test_errors ** 2)),
-            "train/nlpd": -np.mean(train_lds),
-            "test/nlpd": -np.mean(test_lds),
-        }
-        return {k: float(v) for k, v in metrics.items()}
+    """error_logdensity_cb() -> ((train_err, test_err), (train_logdensity, test_logdensity))."""
 
-    return inner_func
+    def reduce() -> Dict[str, float]:
+        errors, logdens = error_logdensity_cb()
+        out = {}
+        for split, err, lpd in zip(("train", "test"), errors, logdens):
+            out[f"{split}/rmse"] = float(np.sqrt(np.mean(np.square(np.asarray(err)))))
+            out[f"{split}/nlpd"] = float(-np.mean(np.asarray(lpd)))
+        return out
+
+    return reduce
