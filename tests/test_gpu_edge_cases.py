@@ -1,0 +1,93 @@
+"""Edge cases of the boundary: tiny and ragged sizes, duplicated points, error codes mapped to the reference's exceptions."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cglb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,D,M", [(1, 1, 1), (2, 3, 2), (17, 1, 3), (63, 2, 5), (65, 8, 8), (257, 4, 16)])
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+def test_tiny_problems_match_oracle(N, D, M, kind):
+    from cglb_amd.hip_context import HipContext
+    X, y, Z = orc.synthetic_problem(max(N, M, 8), D, M, seed=N + M)  # generated larger (z-normalisation needs > 1 point), then cut
+    X, y = X[:N], y[:N]
+    hyp = orc.Hypers(np.full(D, 0.9), 1.3, 0.4, 0.2, Z, 1e-6)
+    ctx = HipContext(X, y, M, kind)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+    v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
+    res = ctx.objective_and_grad(v, True, 1e-6)
+    ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, 1e-6)
+    assert res.steps == ref.steps
+    # two converged solves (1/2 r^T P r <= 1e-6) agree far inside the CG tolerance itself
+    assert res.bound == pytest.approx(ref.bound, rel=1e-9, abs=1e-7)
+    refg = orc.objective(kind, X, y, hyp, v.cpu().numpy(), run_cg=False, with_grad=True).grad
+    np.testing.assert_allclose(res.grad["lengthscales"], refg["lengthscales"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(res.grad["Z"], refg["Z"], rtol=1e-7, atol=1e-9)
+    assert res.grad["noise"] == pytest.approx(refg["noise"], rel=1e-8, abs=1e-10)
+
+
+def test_duplicate_training_points_and_inducing_on_data():
+    """Coincident points: distance exactly 0 (Matern sqrt at 0, gradient finite), inducing points equal to data points."""
+    from cglb_amd.hip_context import HipContext
+    X, y, _ = orc.synthetic_problem(200, 2, 4, seed=3)
+    X[10] = X[11] = X[12]
+    Z = X[[10, 50, 90, 130]].copy()
+    hyp = orc.Hypers(np.array([0.8, 1.2]), 1.0, 0.1, 0.0, Z, 1e-6)
+    for kind in ("rbf", "matern32"):
+        ctx = HipContext(X, y, 4, kind)
+        ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+        v = torch.zeros(200, dtype=torch.float64, device=ctx.device)
+        res = ctx.objective_and_grad(v, True, 1e-4)
+        ref = orc.objective(kind, X, y, hyp, np.zeros(200), True, 1e-4)
+        # the oracle stops with 1/2 r^T P r = 9.8e-5 against the 1e-4 threshold: a last-bit difference decides one more step
+        assert abs(res.steps - ref.steps) <= 1 and res.bound == pytest.approx(ref.bound, abs=2e-4)
+        same_v = orc.objective(kind, X, y, hyp, v.cpu().numpy(), run_cg=False)
+        assert res.bound == pytest.approx(same_v.bound, rel=1e-11)
+        assert np.isfinite(res.grad["Z"]).all() and np.isfinite(res.grad["lengthscales"]).all()
+        refg = orc.objective(kind, X, y, hyp, v.cpu().numpy(), run_cg=False, with_grad=True).grad
+        np.testing.assert_allclose(res.grad["Z"], refg["Z"], rtol=1e-6, atol=1e-8)
+
+
+def test_error_mapping():
+    from cglb_amd.hip_context import HipContext
+    X, y, Z = orc.synthetic_problem(100, 2, 4, seed=1)
+    ctx = HipContext(X, y, 4, "rbf")
+    with pytest.raises(ValueError):
+        ctx.set_hypers(np.array([1.0, -1.0]), 1.0, 0.1, 0.0, Z, 1e-6)          # non-positive lengthscale
+    with pytest.raises(ValueError):
+        ctx.set_hypers(np.ones(2), 1.0, 0.0, 0.0, Z, 1e-6)                       # noise must be positive
+    with pytest.raises(RuntimeError):
+        ctx.setup()                                                              # call order: hypers not set
+    Zdup = Z.copy()
+    Zdup[1] = Zdup[0]
+    ctx.set_hypers(np.ones(2), 1.0, 0.1, 0.0, Zdup, 0.0)                         # singular K_uu, no jitter
+    with pytest.raises(RuntimeError, match="[Cc]holesky"):
+        ctx.setup()                                                              # models.py:202 lets torch.cholesky raise
+    ctx.set_hypers(np.ones(2), 1.0, 0.1, 0.0, Z, 1e-6)
+    ctx.setup()
+    with pytest.raises(ValueError):
+        ctx.matvec(torch.zeros(99, dtype=torch.float64))                         # wrong length
+    with pytest.raises(ValueError):
+        HipContext(X, y[:50], 4, "rbf")
+    with pytest.raises(KeyError):
+        HipContext(X, y, 4, "periodic")
+
+
+def test_warm_start_is_not_mutated_by_solver_and_reused_by_objective():
+    from cglb_amd.hip_context import HipContext
+    X, y, Z = orc.synthetic_problem(500, 3, 16, seed=2)
+    hyp = orc.trained_like_hypers(3, Z)
+    ctx = HipContext(X, y, 16, "rbf")
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, 1e-6)
+    ctx.setup()
+    b = ctx.y - hyp.mean
+    v0 = torch.zeros(500, dtype=torch.float64, device=ctx.device)
+    v1, s1, _ = ctx.pcg(b, v0, 1.0)
+    assert float(v0.abs().max()) == 0.0 and s1 > 0                                # conjugate_gradient.py:55 (clone)
+    v2, s2, _ = ctx.pcg(b, v1, 1.0)
+    assert s2 == 0 and torch.equal(v2, v1)                                        # already converged: predicate fails before any step
+    res = ctx.objective_and_grad(v1.clone(), True, 1.0, with_grad=False)
+    assert res.steps == 0
