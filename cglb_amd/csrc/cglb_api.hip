@@ -167,6 +167,11 @@ int setup_local_impl(cglb_ctx* c) {
     HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (info != 0) return cglb_fail(c, CGLB_ERR_NOT_PD, "cholesky(K_uu + jitter I) failed: leading minor " + std::to_string(info) + " not positive definite");
     CGLB_TRY(launch_tri_clean(c, c->Lc, 1));
+    if (c->precond_mode == 1) {  // explicit L^-1 in both orientations for the implicit preconditioner
+        HIP_CHECK(c, hipMemcpyAsync(c->Linv, c->Lc, (size_t)M * M * c->esz, hipMemcpyDeviceToDevice, c->stream));
+        BLAS_CHECK(c, xtrtri(c->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, M, (T*)c->Linv, M, c->info_dev + 2));
+        CGLB_TRY(launch_transpose(c, c->Linv, c->LinvT));
+    }
     // K_uf shard -> A = L^-1 K_uf / sigma  (models.py:196-197, :206).  Column-major view: At (nloc x M) L^T = Kuf^T / sigma.
     if (c->nloc > 0) {
         CGLB_TRY(launch_kuf(c));
@@ -235,10 +240,30 @@ int setup_finish_impl(cglb_ctx* c) {
     return CGLB_OK;
 }
 
+// u = A r for the local column shard: stored panel (reference form, conjugate_gradient.py:105) or implicitly as
+// sigma^-1 L^-1 (K_uf r) with the tiled pair kernel (no pass over the 819 MB panel)
+int precond_u_any(cglb_ctx* c, const void* r_local, void* u_out) {
+    if (c->precond_mode == 0) return launch_gemv_u(c, r_local, u_out);
+    const char* pcol = (const char*)r_local - (size_t)c->r0 * c->esz;  // the pair kernel indexes columns absolutely
+    CGLB_TRY(launch_pairs_rect(c, c->Zh, c->zah, c->M, c->Xh, c->xah, pcol, c->r0, c->r1, c->w_q));
+    CGLB_TRY(launch_tri_rowdot(c, c->LinvT, c->w_q, 1, u_out));
+    return launch_scale(c, u_out, 1.0 / std::sqrt(c->noise), c->M);
+}
+// z = (r - A^T t)/noise, rz = r^T z (conjugate_gradient.py:110-113); implicit form: A^T t = K_fu (L^-T t / sigma)
+int precond_z_any(cglb_ctx* c, const void* r_local, const void* t, void* z_local, double* rz_slot) {
+    if (c->precond_mode == 0) return launch_precond_z(c, r_local, t, z_local, rz_slot);
+    CGLB_TRY(launch_tri_rowdot(c, c->Linv, t, 0, c->w_q));
+    CGLB_TRY(launch_scale(c, c->w_q, 1.0 / std::sqrt(c->noise), c->M));
+    const char* xrow = (const char*)c->Xh + (size_t)c->r0 * c->Dp * c->esz;
+    const char* arow = (const char*)c->xah + (size_t)c->r0 * c->esz;
+    CGLB_TRY(launch_pairs_rect(c, xrow, arow, c->nloc, c->Zh, c->zah, c->w_q, 0, c->M, c->tpart));
+    return launch_precond_z_from(c, r_local, c->tpart, z_local, rz_slot);
+}
+
 int precond_single(cglb_ctx* c, const void* r, void* z, double* rz_slot) {
-    CGLB_TRY(launch_gemv_u(c, r, c->w_u));
+    CGLB_TRY(precond_u_any(c, r, c->w_u));
     CGLB_TRY(launch_tri_apply(c, c->w_u, c->w_t));
-    CGLB_TRY(launch_precond_z(c, r, c->w_t, z, rz_slot));
+    CGLB_TRY(precond_z_any(c, r, c->w_t, z, rz_slot));
     return CGLB_OK;
 }
 
@@ -296,14 +321,14 @@ int obj_phase1(cglb_ctx* c, const void* v_full, void* u_partial) {
     CGLB_TRY(launch_sub_scalar(c, c->w_e, y_loc, c->mean, c->nloc));       // models.py:253-254
     CGLB_TRY(launch_kff_matvec(c, v_full, c->w_Kv, nullptr));              // :280
     CGLB_TRY(launch_residual(c, c->w_r, c->w_e, c->w_Kv));                 // :281
-    CGLB_TRY(launch_gemv_u(c, c->w_r, u_partial));                         // first half of precon(r), :282
+    CGLB_TRY(precond_u_any(c, c->w_r, u_partial));                         // first half of precon(r), :282
     return CGLB_OK;
 }
 
 int obj_phase2(cglb_ctx* c, const void* v_full, const void* u, double* sc_partial, void* aw_partial) {
     const char* v_loc = (const char*)v_full + (size_t)c->r0 * c->esz;
     CGLB_TRY(launch_tri_apply(c, u, c->w_t));
-    CGLB_TRY(launch_precond_z(c, c->w_r, c->w_t, c->w_z, c->scal + S_TMP));  // w = P r
+    CGLB_TRY(precond_z_any(c, c->w_r, c->w_t, c->w_z, c->scal + S_TMP));  // w = P r
     CGLB_TRY(launch_obj_scalars(c, v_loc, c->w_r, c->w_Kv, c->w_z, sc_partial));
     CGLB_TRY(launch_gemv_u(c, c->w_z, aw_partial));                           // A w  (for c = Kuu^-1 Kuf w)
     return CGLB_OK;
@@ -420,6 +445,8 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     const size_t e = c->esz, N = (size_t)c->N, nl = (size_t)c->nloc, M = (size_t)m, Dp = (size_t)c->Dp;
     CR(dalloc(c, &c->X, N * d * e)); CR(dalloc(c, &c->y, N * e)); CR(dalloc(c, &c->Z, M * d * e));
     CR(dalloc(c, &c->Xs, N * Dp * e)); CR(dalloc(c, &c->xa, N * e)); CR(dalloc(c, &c->Zs, M * Dp * e)); CR(dalloc(c, &c->za, M * e));
+    CR(dalloc(c, &c->Zh, M * Dp * e)); CR(dalloc(c, &c->zah, M * e)); CR(dalloc(c, &c->Linv, M * M * e)); CR(dalloc(c, &c->LinvT, M * M * e));
+    CR(dalloc(c, &c->w_q, M * e));
     CR(dalloc(c, &c->Xh, N * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, (void**)&c->exp_tab, 64 * sizeof(double)));
     {
         double tab[64];
@@ -450,7 +477,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->xah, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
-                    c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items};
+                    c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->blas) (void)rocblas_destroy_handle(c->blas);
     delete c;
@@ -463,6 +490,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "kff_jsplit")) c->kff_jsplit = (int)value;
     else if (!strcmp(name, "kff_rows")) c->kff_rows = (int)value;
     else if (!strcmp(name, "sym_chunk")) c->sym_chunk_opt = value;
+    else if (!strcmp(name, "precond_mode")) { c->precond_mode = (int)value; c->have_local = c->have_terms = false; }
     else return cglb_fail(c, CGLB_ERR_BAD_ARG, std::string("unknown option ") + name);
     return CGLB_OK;
 }
@@ -513,6 +541,7 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xh, c->xah, true));
     CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zs, c->za));
+    CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zh, c->zah, true));
     CGLB_TRY(launch_frag_prep(c));
     c->have_local = c->have_terms = false;
     return CGLB_OK;
@@ -604,14 +633,14 @@ int cglb_shard_precond_u(cglb_ctx* c, const void* r_local, void* u_partial) {
     if (!c || !r_local || !u_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     CGLB_TRY(require_terms(c));
     HIP_CHECK(c, hipSetDevice(c->device));
-    return launch_gemv_u(c, r_local, u_partial);
+    return precond_u_any(c, r_local, u_partial);
 }
 int cglb_shard_precond_z(cglb_ctx* c, const void* r_local, const void* u, void* z_local, void* rz_partial) {
     if (!c || !r_local || !u || !z_local || !rz_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     CGLB_TRY(require_terms(c));
     HIP_CHECK(c, hipSetDevice(c->device));
     CGLB_TRY(launch_tri_apply(c, u, c->w_t));
-    return launch_precond_z(c, r_local, c->w_t, z_local, (double*)rz_partial);
+    return precond_z_any(c, r_local, c->w_t, z_local, (double*)rz_partial);
 }
 
 int cglb_shard_dot(cglb_ctx* c, const void* a_local, const void* b_local, void* out) {
@@ -682,7 +711,7 @@ int cglb_shard_obj_phase1_kv(cglb_ctx* c, const void* Kv_local, void* u_partial)
     CGLB_TRY(launch_sub_scalar(c, c->w_e, y_loc, c->mean, c->nloc));
     HIP_CHECK(c, hipMemcpyAsync(c->w_Kv, Kv_local, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
     CGLB_TRY(launch_residual(c, c->w_r, c->w_e, c->w_Kv));
-    return launch_gemv_u(c, c->w_r, u_partial);
+    return precond_u_any(c, c->w_r, u_partial);
 }
 int cglb_shard_obj_w(cglb_ctx* c, void* w_local_out) {
     if (!c || !w_local_out) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;

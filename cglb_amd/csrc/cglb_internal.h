@@ -32,6 +32,12 @@ struct cglb_ctx {
     double var = 1, noise = 1, mean = 0, jitter = 1e-6;
     // scaled operands of the streaming kernels (T): xs = (x-c)/l*kscale padded to Dp, xa = per-row norm term
     void *Xs = nullptr, *xa = nullptr, *Zs = nullptr, *za = nullptr;
+    void *Zh = nullptr, *zah = nullptr;  // hot-scaled inducing points (implicit preconditioner)
+    void *Linv = nullptr, *LinvT = nullptr;  // L^-1 (column-major lower) and its transpose (implicit preconditioner)
+    void* w_q = nullptr;                 // [M] scratch
+    void* ppart = nullptr;               // partial slab of launch_pairs_rect
+    size_t ppart_cap = 0;
+    int precond_mode = 0;                // 0: stored panel A (reference form), 1: implicit K_uf products
     void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/64 octave (devmath.h exp2_tab)
     double* exp_tab = nullptr;           // device table 2^(k/64), k < 64
     // common terms (column-major M x M unless noted)
@@ -125,6 +131,11 @@ int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partia
 int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, double* out_dl);
 int launch_kff_plain_range(cglb_ctx* c, const void* p_full, int64_t col0, int64_t col1, void* part, int64_t* nslots);
 int launch_kff_mfma_pairs(cglb_ctx* c, const double* p_full, int64_t* jsplit_out);
+int launch_pairs_rect(cglb_ctx* c, const void* XsRow, const void* xaRow, int64_t nrows, const void* XsCol, const void* xaCol, const void* pcol,
+                      int64_t col0, int64_t col1, void* out);
+int launch_tri_rowdot(cglb_ctx* c, const void* Wrows, const void* x, int lower, void* out);
+int launch_scale(cglb_ctx* c, void* x, double a, int64_t n);
+int launch_precond_z_from(cglb_ctx* c, const void* r_local, const void* Ks_local, void* z_local, double* rz_slot);
 int launch_cross_matvec(cglb_ctx* c, const void* Xs_new, const void* xa_new, int64_t n_new, const void* v_full, void* out);
 // kernels_vec.hip
 int launch_dot(cglb_ctx* c, const void* a, const void* b, int64_t n, double* out_slot);

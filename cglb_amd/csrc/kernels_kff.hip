@@ -117,7 +117,8 @@ static inline int rows_per_thread(const cglb_ctx* c) {
 // Launches the plain pair kernel for rows (XsRow, xaRow, nrows) against columns [col0, col1) into `part` ([slots][nrows]).
 template <typename T, int KIND, int DP>
 static int kff_pairs_range(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrows, const T* p_full, int64_t col0, int64_t col1, T* part,
-                           int64_t max_slots, int64_t* nslots) {
+                           int64_t max_slots, int64_t* nslots, const T* XsCol = nullptr, const T* xaCol = nullptr) {
+    if (!XsCol) { XsCol = (const T*)c->Xh; xaCol = (const T*)c->xah; }  // default column operand: the training inputs
     const int R = rows_per_thread(c);
     const int64_t ncols = col1 - col0;
     const int64_t bx = (nrows + 256 * R - 1) / (256 * R);
@@ -134,11 +135,11 @@ static int kff_pairs_range(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t 
     do {                                                                                                             \
         if (c->exp_clamp)                                                                                            \
             hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, true>), grid, dim3(256), 0, c->stream, XsRow,      \
-                               xaRow, nrows, (const T*)c->Xh, (const T*)c->xah, p_full, col0, col1, jchunk, part, \
+                               xaRow, nrows, XsCol, xaCol, p_full, col0, col1, jchunk, part,                          \
                                (const double*)c->exp_tab);                                                          \
         else                                                                                                         \
             hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, false>), grid, dim3(256), 0, c->stream, XsRow,     \
-                               xaRow, nrows, (const T*)c->Xh, (const T*)c->xah, p_full, col0, col1, jchunk, part, \
+                               xaRow, nrows, XsCol, xaCol, p_full, col0, col1, jchunk, part,                          \
                                (const double*)c->exp_tab);                                                          \
     } while (0)
     if (R == 4) { if constexpr (DP <= 8) KFF_LAUNCH(4); else if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
@@ -163,6 +164,38 @@ static int kff_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrow
     int64_t jsplit = 1;
     CGLB_TRY((kff_pairs_range<T, KIND, DP>(c, XsRow, xaRow, nrows, p_full, 0, c->N, (T*)c->kpart, 512, &jsplit)));
     return kff_combine<T>(c, jsplit, nrows, out, pdiag, noise, pdot_slot);
+}
+
+// Rectangular kernel product with explicit row and column operands (hot-scaled):
+//   out[i] = var * sum_{j in [col0,col1)} kappa(row_i, col_j) pcol[j]      (pcol is indexed by the absolute column index)
+// Used by the implicit Nystrom preconditioner (K_uf r and K_fu s).
+int launch_pairs_rect(cglb_ctx* c, const void* XsRow, const void* xaRow, int64_t nrows, const void* XsCol, const void* xaCol, const void* pcol,
+                      int64_t col0, int64_t col1, void* out) {
+    if (nrows == 0) return CGLB_OK;
+    const size_t need = (size_t)512 * nrows * c->esz;
+    if (need > c->ppart_cap) {
+        if (c->ppart) HIP_CHECK(c, hipFree(c->ppart));
+        c->ppart = nullptr;
+        HIP_CHECK(c, hipMalloc(&c->ppart, need));
+        c->ppart_cap = need;
+    }
+    if (col1 <= col0) {
+        HIP_CHECK(c, hipMemsetAsync(out, 0, (size_t)nrows * c->esz, c->stream));
+        return CGLB_OK;
+    }
+    int64_t ns = 1;
+    const bool saved = c->exp_clamp;
+    c->exp_clamp = true;  // inducing points may lie outside the training range
+    int rc = CGLB_OK;
+    CGLB_DISPATCH_ALL(c, rc = (kff_pairs_range<T, KIND, DP>(c, (const T*)XsRow, (const T*)xaRow, nrows, (const T*)pcol, col0, col1, (T*)c->ppart, 512,
+                                                            &ns, (const T*)XsCol, (const T*)xaCol)));
+    c->exp_clamp = saved;
+    CGLB_TRY(rc);
+    const int cgrid = (int)((nrows + 255) / 256);
+    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((kff_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)c->ppart, (int)ns, nrows,
+                                                 (T)c->var, (T)0, (const T*)nullptr, (T*)out, (double*)nullptr));
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
 }
 
 // plain pair kernel of the local row shard against columns [col0, col1) (used by the symmetric path for the

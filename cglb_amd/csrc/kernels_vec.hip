@@ -219,6 +219,25 @@ __global__ __launch_bounds__(256) void tri_rowdot_kernel(const T* __restrict__ W
     if (lane == 0) out[wave] = (T)s;
 }
 
+int launch_tri_rowdot(cglb_ctx* c, const void* Wrows, const void* x, int lower, void* out) {
+    const int grid = (c->M * 64 + 255) / 256;
+    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((tri_rowdot_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (const T*)Wrows, (const T*)x, c->M,
+                                                 lower, (T*)out));
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ x, T a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= a;
+}
+int launch_scale(cglb_ctx* c, void* x, double a, int64_t n) {
+    if (n == 0) return CGLB_OK;
+    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((scale_kernel<T>), dim3(vec_grid(n, 256)), dim3(256), 0, c->stream, (T*)x, (T)a, n));
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
 int launch_tri_apply(cglb_ctx* c, const void* u, void* t_out) {
     const int grid = (c->M * 64 + 255) / 256;
     // y = LB^-1 u : rows of LB^-1 are contiguous in LBinvT's column-major storage (== row-major LB^-1)
@@ -267,6 +286,17 @@ __global__ __launch_bounds__(256) void precond_z_kernel(const T* __restrict__ r,
     }
     acc = block_sum(acc, smem);
     if (threadIdx.x == 0) dotpart[blockIdx.x] = acc;
+}
+
+// z = (r - Ks)/noise, rz = sum (r - Ks) r / noise, with Ks = A^T t already formed (implicit preconditioner)
+int launch_precond_z_from(cglb_ctx* c, const void* r_local, const void* Ks_local, void* z_local, double* rz_slot) {
+    const int g2 = vec_grid(c->nloc, 256);
+    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((precond_z_kernel<T>), dim3(g2), dim3(256), 0, c->stream, (const T*)r_local,
+                                                 (const T*)Ks_local, 1, c->nloc, (T)(1.0 / c->noise), (T*)z_local, c->dotpart));
+    CGLB_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(finalize_sum_kernel2, dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, g2, rz_slot, 1.0 / c->noise);
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
 }
 
 int launch_precond_z(cglb_ctx* c, const void* r_local, const void* t, void* z_local, double* rz_slot) {

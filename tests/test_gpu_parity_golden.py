@@ -91,3 +91,24 @@ def test_bound_and_gradient_at_reference_v(name):
         if key == "mean":
             tol = 1e-11 * np.abs(g["v"]).sum()
         np.testing.assert_allclose(np.asarray(res.grad[key]), ref, rtol=1e-7, atol=tol, err_msg=key)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_implicit_preconditioner_matches_reference(name):
+    """precond_mode = 1: A r and A^T t formed as sigma^-1 L^-1 (K_uf r) / K_fu (L^-T t)/sigma with the tiled pair kernel."""
+    g = load_golden(name)
+    from cglb_amd.hip_context import HipContext
+    hyp = golden_hypers(g)
+    ctx = HipContext(g["X"], g["y"], hyp.Z.shape[0], int(g["kind"]))
+    ctx.set_option("precond_mode", 1)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, hyp.Z, hyp.jitter)
+    ctx.setup()
+    z, rz = ctx.precond(torch.from_numpy(g["r_test"]))
+    np.testing.assert_allclose(z.cpu().numpy(), g["z_test"], rtol=0, atol=1e-9 * np.abs(g["z_test"]).max())
+    assert rz == pytest.approx(float(g["rz_test"]), rel=1e-9)
+    v = torch.from_numpy(g["v0"]).to(ctx.device).clone()
+    res = ctx.objective_and_grad(v, True, float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+    assert abs(res.steps - int(g["steps"])) <= (0 if int(g["steps"]) <= 40 else 1)
+    assert res.bound == pytest.approx(float(g["bound"]), rel=1e-6)
+    if res.steps == int(g["steps"]) and res.steps <= 20:
+        assert res.bound == pytest.approx(float(g["bound"]), rel=1e-9)
