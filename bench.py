@@ -111,9 +111,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CGLB_BENCH_FORCE_DIST=1: run the distributed driver and issue its collectives even at world_size 1 (rehearses the RCCL calls
+    # on a one-GPU box; never set by the real runs)
+    force_dist = os.environ.get("CGLB_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
         else:
@@ -126,19 +133,19 @@ def main():
 
     per, parts = row_partition(N, world)
     ctx = HipContext(X, y, M, kind, device=dev, row_range=parts[rank])
-    comm = Comm()
+    comm = Comm(force=force_dist)
     # N > 1: cyclic-symmetric scheme (each kernel value used twice, global upper triangle dealt to the ranks by 256-row blocks)
-    drv = SymShardedCGLB(HipSymLocalOps(ctx), comm) if world > 1 else None
+    drv = SymShardedCGLB(HipSymLocalOps(ctx), comm) if use_dist else None
     v = torch.zeros(N, dtype=torch.float64, device=dev)
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     def one_step():
-        if world == 1:
+        if not use_dist:
             v.zero_()
             return ctx.objective_and_grad(v, True, cg["max_error"], cg["max_cg_iter"], cg["restart_cg_iter"], with_grad=True)
         drv.v.zero_()
@@ -156,7 +163,7 @@ def main():
             res = one_step()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -176,7 +183,7 @@ def main():
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the library's stream -------------
     ctx.setup_local()
-    if world > 1:
+    if use_dist:
         comm.allreduce(ctx.aat_tensor())
     ctx.setup_finish()
     reps = 10
@@ -230,7 +237,7 @@ def main():
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(record))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -37,19 +37,21 @@ def row_partition(n: int, world: int) -> Tuple[int, list]:
 class Comm:
     """The two collectives the path needs.  world == 1 -> no-ops."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force: bool = False):
+        """force=True issues the collectives even at world_size 1 (used to exercise the RCCL calls on a one-GPU box)."""
         self.group = group
         self.active = dist is not None and dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
+        self.force = bool(force) and self.active
 
     def allreduce(self, t: torch.Tensor) -> None:
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def allgather_inplace(self, buf: torch.Tensor, per: int) -> None:
         """buf has world*per elements; rank g's slice buf[g*per:(g+1)*per] is valid on rank g."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         mine = buf[self.rank * per:(self.rank + 1) * per]
         try:
@@ -326,7 +328,7 @@ class SymShardedCGLB:
 
     def setup(self):
         self.ops.setup_local()
-        if self.comm.world > 1:
+        if self.comm.world > 1 or self.comm.force:
             self.comm.allreduce(self.ops.aat_tensor())
         self.ops.setup_finish()
 
