@@ -161,7 +161,8 @@ int setup_local_impl(cglb_ctx* c) {
     const int M = c->M;
     // K_uu + jitter I -> L (models.py:200-202)
     CGLB_TRY(launch_kuu(c));
-    BLAS_CHECK(c, xpotrf(c->blas, rocblas_fill_lower, M, (T*)c->Lc, M, c->info_dev));
+    if (c->chol_mode == 1) CGLB_TRY(launch_cholesky_lower(c, c->Lc, (int*)c->info_dev));  // blocked LDS Cholesky (kernels_chol.hip)
+    else BLAS_CHECK(c, xpotrf(c->blas, rocblas_fill_lower, M, (T*)c->Lc, M, c->info_dev));
     rocblas_int info = 0;
     HIP_CHECK(c, hipMemcpyAsync(&info, c->info_dev, sizeof(info), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -220,7 +221,8 @@ int setup_finish_impl(cglb_ctx* c) {
     // B = AA^T + I, LB = chol(B), tr(AA^T)  (models.py:208-211)
     HIP_CHECK(c, hipMemcpyAsync(c->LBc, c->AAt, mm, hipMemcpyDeviceToDevice, c->stream));
     CGLB_TRY(launch_add_identity_trace(c, c->LBc, c->scal + S_TRACE));
-    BLAS_CHECK(c, xpotrf(c->blas, rocblas_fill_lower, M, (T*)c->LBc, M, c->info_dev));
+    if (c->chol_mode == 1) CGLB_TRY(launch_cholesky_lower(c, c->LBc, (int*)c->info_dev));
+    else BLAS_CHECK(c, xpotrf(c->blas, rocblas_fill_lower, M, (T*)c->LBc, M, c->info_dev));
     CGLB_TRY(launch_tri_clean(c, c->LBc, 1));
     CGLB_TRY(launch_sum_log_diag(c, c->LBc, c->scal + S_SUMLOG));
     // explicit triangular inverse of LB in both orientations (contiguous rows for the two products of
@@ -477,7 +479,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->xah, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
-                    c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart};
+                    c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->blas) (void)rocblas_destroy_handle(c->blas);
     delete c;
@@ -490,6 +492,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "kff_jsplit")) c->kff_jsplit = (int)value;
     else if (!strcmp(name, "kff_rows")) c->kff_rows = (int)value;
     else if (!strcmp(name, "sym_chunk")) c->sym_chunk_opt = value;
+    else if (!strcmp(name, "chol_mode")) c->chol_mode = (int)value;
     else if (!strcmp(name, "precond_mode")) { c->precond_mode = (int)value; c->have_local = c->have_terms = false; }
     else return cglb_fail(c, CGLB_ERR_BAD_ARG, std::string("unknown option ") + name);
     return CGLB_OK;

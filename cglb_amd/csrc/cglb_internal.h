@@ -37,6 +37,8 @@ struct cglb_ctx {
     void* w_q = nullptr;                 // [M] scratch
     void* ppart = nullptr;               // partial slab of launch_pairs_rect
     size_t ppart_cap = 0;
+    void* chol_blk = nullptr;            // dense copy of the current diagonal block + reciprocal diagonal (kernels_chol.hip)
+    int chol_mode = 1;                   // 1: blocked LDS Cholesky (kernels_chol.hip), 0: rocSOLVER potrf
     int precond_mode = 0;                // 0: stored panel A (reference form), 1: implicit K_uf products
     void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/64 octave (devmath.h exp2_tab)
     double* exp_tab = nullptr;           // device table 2^(k/64), k < 64
@@ -125,6 +127,7 @@ int launch_kuf(cglb_ctx* c);  // At <- Kuf[:, rows] (unscaled by sigma)
 int launch_kuu(cglb_ctx* c);  // Lc <- Kuu + jitter I (full symmetric)
 // kernels_kff.hip
 int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
+int launch_cholesky_lower(cglb_ctx* c, void* A, int* info_slot);
 int launch_frag_prep(cglb_ctx* c);
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
 int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial);  // this rank's share of the global upper triangle
