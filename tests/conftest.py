@@ -14,6 +14,20 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    _ensure_built()
+
+
+def _ensure_built():
+    """Build the native pieces if a fresh checkout has none yet (hipcc cross-compiles without a GPU; the built .so files
+    travel to the GPU box with the snapshot).  Same recipe as __graft_entry__.build()."""
+    import subprocess
+    hip_so = os.path.join(ROOT, "cglb_amd", "lib", "libcglb_hip.so")
+    orc_so = os.path.join(ROOT, "oracle", "_build", "libcglb_oracle.so")
+    if not os.path.exists(hip_so):
+        subprocess.run(["make", "-j", str(min(8, os.cpu_count() or 1)), "-C", os.path.join(ROOT, "cglb_amd", "csrc")], check=True,
+                       capture_output=True)
+    if not os.path.exists(orc_so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
 
 
 def golden_names():
