@@ -17,7 +17,8 @@ OK, ERR_BAD_ARG, ERR_NOT_PD, ERR_HIP, ERR_BLAS, ERR_STATE = range(6)
 RBF, MATERN32 = 0, 1
 F64, F32 = 0, 1
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcglb_hip.so")
+# CGLB_HIP_LIB lets a developer point at an experimental build of the same ABI (tools/ only; there is still no CPU fallback)
+_LIB_PATH = os.environ.get("CGLB_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcglb_hip.so")
 
 #: every symbol include/cglb_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {

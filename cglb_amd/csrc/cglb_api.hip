@@ -449,11 +449,11 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     CR(dalloc(c, &c->Xs, N * Dp * e)); CR(dalloc(c, &c->xa, N * e)); CR(dalloc(c, &c->Zs, M * Dp * e)); CR(dalloc(c, &c->za, M * e));
     CR(dalloc(c, &c->Zh, M * Dp * e)); CR(dalloc(c, &c->zah, M * e)); CR(dalloc(c, &c->Linv, M * M * e)); CR(dalloc(c, &c->LinvT, M * M * e));
     CR(dalloc(c, &c->w_q, M * e));
-    CR(dalloc(c, &c->Xh, N * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, (void**)&c->exp_tab, 64 * sizeof(double)));
+    CR(dalloc(c, &c->Xh, N * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, (void**)&c->exp_tab, CGLB_TAB_SIZE * sizeof(double)));
     {
-        double tab[64];
-        for (int k = 0; k < 64; ++k) tab[k] = std::exp2((double)k / 64.0);  // glibc exp2 is correctly rounded to < 1 ulp
-        hipError_t e3 = hipMemcpy(c->exp_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
+        std::vector<double> tab(CGLB_TAB_SIZE);
+        for (int k = 0; k < CGLB_TAB_SIZE; ++k) tab[k] = std::exp2((double)k / (double)CGLB_TAB_SIZE);  // glibc exp2: < 1 ulp
+        hipError_t e3 = hipMemcpy(c->exp_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e3 != hipSuccess) { c->err = "exp table upload failed"; return fail(CGLB_ERR_HIP); }
     }
     CR(dalloc(c, &c->At, M * (size_t)c->lda * e));

@@ -40,7 +40,7 @@ struct cglb_ctx {
     void* chol_blk = nullptr;            // dense copy of the current diagonal block + reciprocal diagonal (kernels_chol.hip)
     int chol_mode = 1;                   // 1: blocked LDS Cholesky (kernels_chol.hip), 0: rocSOLVER potrf
     int precond_mode = 0;                // 0: stored panel A (reference form), 1: implicit K_uf products
-    void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/64 octave (devmath.h exp2_tab)
+    void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/T octave, T = 2^CGLB_TAB_BITS (devmath.h exp2_tab)
     double* exp_tab = nullptr;           // device table 2^(k/64), k < 64
     // common terms (column-major M x M unless noted)
     void* At = nullptr;      // A as [M][nloc] row-major == (nloc x M) column-major, ld = nloc

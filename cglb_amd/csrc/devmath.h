@@ -86,29 +86,56 @@ __device__ __forceinline__ double sqrt_hot(double x) {
 }
 __device__ __forceinline__ float sqrt_hot(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
 
-// Table-driven 2^(x/64): the hot pair kernels keep their operands in units of 1/64 octave (x64 = 64*log2 of the value), so
-//   x64 = n + s, |s| <= 1/2;  2^(x64/64) = 2^(n>>6) * TAB[n & 63] * P5(s),  TAB[k] = 2^(k/64) (correctly rounded, in LDS),
-//   P5 = degree-5 polynomial for 2^(s/64) (1.1e-16).  Total error <= ~3e-16 (1.5 ulp).
-// 10 vector-fp64 instructions (rndne, add, 5 fma, cvt, mul, ldexp) + 3 cheap 32-bit integer ops + one ds_read_b64, against
-// 14 for the pure polynomial form: fp64 has no hardware transcendental on CDNA, and the pair kernels are bound by
-// vector-fp64 issue, so every instruction here is ~4 % of the mat-vec.
-#define CGLB_HOT_UNITS 64.0
-template <bool CLAMP> __device__ __forceinline__ double exp2_tab(double x64, const double* __restrict__ tab_lds) {
-    if (CLAMP) x64 = fmax(x64, -70400.0);
-    const double n = __builtin_rint(x64);
-    const double s = x64 - n;
-    const int ni = (int)n;
-    const double t = tab_lds[ni & 63];
-    double p = 0x1.5d8855325a3d0p-40;
-    p = __builtin_fma(p, s, 0x1.3b2ad54ddd7adp-31);
-    p = __builtin_fma(p, s, 0x1.c6b08d7044d9dp-23);
-    p = __builtin_fma(p, s, 0x1.ebfbdff829821p-15);
-    p = __builtin_fma(p, s, 0x1.62e42fefa39efp-7);
-    p = __builtin_fma(p, s, 1.0);
-    return __builtin_ldexp(t * p, ni >> 6);
+__device__ __forceinline__ double tfma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float tfma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Table-driven 2^(xh/T), T = 2^CGLB_TAB_BITS: the hot pair kernels keep their operands in units of 1/T octave (xh = T*log2 of the
+// value), so  xh = n + s, |s| <= 1/2;  2^(xh/T) = 2^(n >> BITS) * TAB[n & (T-1)] * P(s),  TAB[k] = 2^(k/T) (correctly rounded, in LDS),
+//   P = polynomial for 2^(s/T) (1.1e-16).  Total error <= ~3e-16 (1.5 ulp).
+// fp64 has no hardware transcendental on CDNA and the pair kernels are bound by vector-fp64 issue, so every instruction here is
+// ~4 % of the mat-vec: with T = 256 this is 9 vector-fp64 instructions (rndne, add, 4 fma, cvt, mul, ldexp) + 3 cheap 32-bit
+// integer ops + one ds_read_b64, against 14 for the pure polynomial form.
+// Table size is a build-time choice: 6 -> 64 entries (512 B) + degree 5, 8 -> 256 entries (2 KB) + degree 4 (default),
+// 12 -> 4096 entries (32 KB) + degree 3.  Each step trades one fma per pair for LDS footprint and bank conflicts; measured
+// mat-vec at N = 100k, D = 8 (MI355X): 3.69 / 3.47 / 3.45 ms - beyond 256 entries the random-index ds_read_b64 (one per pair,
+// four SIMDs sharing the CU's LDS port) eats the fma that the shorter polynomial saves.
+#ifndef CGLB_TAB_BITS
+#define CGLB_TAB_BITS 8
+#endif
+#define CGLB_TAB_SIZE (1 << CGLB_TAB_BITS)
+#define CGLB_HOT_UNITS ((double)CGLB_TAB_SIZE)
+// P(s) = 2^(s / TAB_SIZE) on |s| <= 1/2 (max rel. error 1.1e-16 for each variant, fitted on Chebyshev nodes in extended precision)
+template <typename T> __device__ __forceinline__ T exp2_tab_poly(T s) {
+#if CGLB_TAB_BITS == 6
+    T p = T(0x1.5d8855325a3d0p-40);
+    p = tfma_(p, s, T(0x1.3b2ad54ddd7adp-31));
+    p = tfma_(p, s, T(0x1.c6b08d7044d9dp-23));
+    p = tfma_(p, s, T(0x1.ebfbdff829821p-15));
+    p = tfma_(p, s, T(0x1.62e42fefa39efp-7));
+#elif CGLB_TAB_BITS == 8
+    T p = T(0x1.3b2ad0e3ae6d5p-39);
+    p = tfma_(p, s, T(0x1.c6b090db83bfbp-29));
+    p = tfma_(p, s, T(0x1.ebfbdff82beffp-19));
+    p = tfma_(p, s, T(0x1.62e42fefa39b8p-9));
+#elif CGLB_TAB_BITS == 12
+    T p = T(0x1.c6b0809952670p-41);
+    p = tfma_(p, s, T(0x1.ebfbdffd0ae72p-27));
+    p = tfma_(p, s, T(0x1.62e42fefa39f0p-13));
+#else
+#error "CGLB_TAB_BITS must be 6, 8 or 12"
+#endif
+    return tfma_(p, s, T(1));
 }
-template <bool CLAMP> __device__ __forceinline__ float exp2_tab(float x64, const double* __restrict__) {
-    return __builtin_amdgcn_exp2f(x64 * (1.0f / 64.0f));
+template <bool CLAMP> __device__ __forceinline__ double exp2_tab(double xh, const double* __restrict__ tab_lds) {
+    if (CLAMP) xh = fmax(xh, -1100.0 * CGLB_TAB_SIZE);
+    const double n = __builtin_rint(xh);
+    const double s = xh - n;
+    const int ni = (int)n;
+    const double t = tab_lds[ni & (CGLB_TAB_SIZE - 1)];
+    return __builtin_ldexp(t * exp2_tab_poly<double>(s), ni >> CGLB_TAB_BITS);
+}
+template <bool CLAMP> __device__ __forceinline__ float exp2_tab(float xh, const double* __restrict__) {
+    return __builtin_amdgcn_exp2f(xh * (1.0f / (float)CGLB_TAB_SIZE));
 }
 
 template <typename T> __device__ __forceinline__ T tfma(T a, T b, T c);
@@ -135,7 +162,7 @@ template <typename T, int KIND, bool CLAMP> __device__ __forceinline__ T kappa_f
     }
 }
 
-// Hot-unit forms (operands scaled so that exponents are in 1/64 octave, see exp2_tab):
+// Hot-unit forms (operands scaled so that exponents are in 1/T octave, see exp2_tab):
 //   RBF:      xh = 8 xs, ah = 64 a          kappa = 2^((ah_i + ah_j + xh_i.xh_j)/64)
 //   Matern32: xh = 64 xs, ah = 4096 a       r64 = sqrt(max(ah_i + ah_j - 2 xh_i.xh_j, 0)),  kappa = (1 + r64 ln2/64) 2^(-r64/64)
 template <typename T, int KIND, bool CLAMP>
@@ -164,26 +191,21 @@ __device__ __forceinline__ KappaPend<T> kappa_hot_begin(T gram, T aj, const doub
         k.lin = tfma<T>(r, T(CGLB_LN2 / CGLB_HOT_UNITS), T(1));
         x64 = -r;
     }
-    if (CLAMP) x64 = tmax<T>(x64, T(-70400.0));
+    if (CLAMP) x64 = tmax<T>(x64, T(-1100.0 * CGLB_TAB_SIZE));
     const T n = __builtin_rint(x64);
     k.s = x64 - n;
     k.ni = (int)n;
-    k.tabv = (T)tab[k.ni & 63];
+    k.tabv = (T)tab[k.ni & (CGLB_TAB_SIZE - 1)];
     return k;
 }
 // polynomial part (independent of the table read): overwrites k.s with P5(s) [* lin for Matern]
 template <typename T, int KIND> __device__ __forceinline__ void kappa_hot_poly(KappaPend<T>& k) {
-    T p = T(0x1.5d8855325a3d0p-40);
-    p = tfma<T>(p, k.s, T(0x1.3b2ad54ddd7adp-31));
-    p = tfma<T>(p, k.s, T(0x1.c6b08d7044d9dp-23));
-    p = tfma<T>(p, k.s, T(0x1.ebfbdff829821p-15));
-    p = tfma<T>(p, k.s, T(0x1.62e42fefa39efp-7));
-    p = tfma<T>(p, k.s, T(1));
+    T p = exp2_tab_poly<T>(k.s);
     if (KIND != CGLB_RBF) p *= k.lin;
     k.s = p;
 }
 template <typename T, int KIND> __device__ __forceinline__ T kappa_hot_end(const KappaPend<T>& k) {
-    return __builtin_ldexp(k.tabv * k.s, k.ni >> 6);
+    return __builtin_ldexp(k.tabv * k.s, k.ni >> CGLB_TAB_BITS);
 }
 
 // gradient factor from an exact squared distance in hot units (RBF: d2h = 64 d2s; Matern32: d2h = 4096 d2s)
@@ -194,9 +216,9 @@ template <typename T, int KIND, bool CLAMP> __device__ __forceinline__ T hfac_ho
         return T(3) * exp2_tab<CLAMP>(-sqrt_pos(d2h), tab);
     }
 }
-// cooperative load of the 64-entry table into LDS (call from every thread of the block, before any early exit)
+// cooperative load of the exp2 table into LDS (call from every thread of the block, before any early exit)
 __device__ __forceinline__ void load_exp_table(double* tab_lds, const double* __restrict__ tab_global) {
-    if (threadIdx.x < 64) tab_lds[threadIdx.x] = tab_global[threadIdx.x];
+    for (int i = threadIdx.x; i < CGLB_TAB_SIZE; i += blockDim.x) tab_lds[i] = tab_global[i];
     __syncthreads();
 }
 

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
                                                        int rb_stride, int rb_offset, double* __restrict__ part,
                                                        const double* __restrict__ exp_tab) {
     __shared__ double smem[16];
-    __shared__ double tab[64];
+    __shared__ double tab[CGLB_TAB_SIZE];
     load_exp_table(tab, exp_tab);
     const int64_t rblock = ((int64_t)blockIdx.x * rb_stride + rb_offset) * (256 * R);  // cyclic over ranks when rb_stride > 1
     const int64_t rbase = rblock + threadIdx.x;

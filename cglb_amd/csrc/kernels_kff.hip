@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ X
                                                          const T* __restrict__ xa, const T* __restrict__ p, int64_t col0,
                                                          int64_t col1, int64_t jchunk, T* __restrict__ part,
                                                          const double* __restrict__ exp_tab) {
-    __shared__ double tab[64];
+    __shared__ double tab[CGLB_TAB_SIZE];
     load_exp_table(tab, exp_tab);
     const int64_t rbase = (int64_t)blockIdx.x * (256 * R) + threadIdx.x;
     T xi[R][DP], ai[R], acc[R];

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items, int nitems,
                                                       int rb_stride, T* __restrict__ Prow, T* __restrict__ Pcol,
                                                       const double* __restrict__ exp_tab) {
-    __shared__ double tab[64];
+    __shared__ double tab[CGLB_TAB_SIZE];
     load_exp_table(tab, exp_tab);  // before the early exit below: every thread reaches the barrier inside
     const int lane = threadIdx.x & 63;
     // wave-uniform work item: readfirstlane makes that visible to the compiler, so everything derived from it

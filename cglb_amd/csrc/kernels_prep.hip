@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void prep_scaled_kernel(const T* __restrict__ 
     xa[i] = (KIND == CGLB_RBF) ? T(-0.5) * s2 : s2;
 }
 
-// hot operand set: RBF exponent -|xh_i-xh_j|^2/2 and Matern exponent -|xh_i-xh_j| are in 1/64 octave
+// hot operand set: RBF exponent -|xh_i-xh_j|^2/2 and Matern exponent -|xh_i-xh_j| are in 1/T octave (T = 2^CGLB_TAB_BITS)
 double cglb_hot_scale(const cglb_ctx* c) { return (c->kind == CGLB_RBF) ? sqrt(CGLB_HOT_UNITS) : CGLB_HOT_UNITS; }
 
 int launch_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out, bool hot) {
