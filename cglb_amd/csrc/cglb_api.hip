@@ -449,10 +449,16 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     CR(dalloc(c, &c->Xs, N * Dp * e)); CR(dalloc(c, &c->xa, N * e)); CR(dalloc(c, &c->Zs, M * Dp * e)); CR(dalloc(c, &c->za, M * e));
     CR(dalloc(c, &c->Zh, M * Dp * e)); CR(dalloc(c, &c->zah, M * e)); CR(dalloc(c, &c->Linv, M * M * e)); CR(dalloc(c, &c->LinvT, M * M * e));
     CR(dalloc(c, &c->w_q, M * e));
-    CR(dalloc(c, &c->Xh, N * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, (void**)&c->exp_tab, CGLB_TAB_SIZE * sizeof(double)));
+    CR(dalloc(c, &c->Xh, N * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, &c->wh, N * e)); CR(dalloc(c, &c->pwh, N * e)); CR(dalloc(c, (void**)&c->exp_tab, CGLB_TAB_SIZE * sizeof(double)));
     {
         std::vector<double> tab(CGLB_TAB_SIZE);
-        for (int k = 0; k < CGLB_TAB_SIZE; ++k) tab[k] = std::exp2((double)k / (double)CGLB_TAB_SIZE);  // glibc exp2: < 1 ulp
+        for (int k = 0; k < CGLB_TAB_SIZE; ++k) {
+            const double v = std::exp2((double)k / (double)CGLB_TAB_SIZE);  // glibc exp2: < 1 ulp
+            uint64_t bits;
+            std::memcpy(&bits, &v, 8);
+            bits -= (uint64_t)k << (52 - CGLB_TAB_BITS);  // pre-compensated for the one-add scaling (devmath.h exp2_tab_scale)
+            std::memcpy(&tab[k], &bits, 8);
+        }
         hipError_t e3 = hipMemcpy(c->exp_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e3 != hipSuccess) { c->err = "exp table upload failed"; return fail(CGLB_ERR_HIP); }
     }
@@ -477,7 +483,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     if (!c) return CGLB_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->xah, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
+    void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->xah, c->wh, c->pwh, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
                     c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -535,14 +541,20 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
     c->var = variance; c->noise = noise; c->mean = mean; c->jitter = jitter;
     HIP_CHECK(c, hipMemcpyAsync(c->Z, Z, (size_t)c->M * c->D * c->esz, hipMemcpyDefault, c->stream));
     c->have_hypers = true;
-    {   // bound on |a_i + a_j + xs_i.xs_j| <= 2 max|xs|^2 ; the unclamped 2^x of the hot loops needs it < 2^30
+    {   // |a_i + a_j + xs_i.xs_j| <= 2 max|xs|^2 (scaled units: octaves for RBF, octaves^2 for Matern).  The unclamped 2^x of
+        // the hot loops needs the exponent inside [-1000, 0] octaves (exp2_tab_scale) and its hot-unit integer below 2^30.
         const double ks = (c->kind == CGLB_RBF) ? std::sqrt(CGLB_LOG2E) : CGLB_SQRT3 * CGLB_LOG2E;
         double s2 = 0.0;
         for (int d = 0; d < c->D; ++d) { const double v = c->xrange[d] * ks / c->ls[d]; s2 += v * v; }
-        c->exp_clamp = !(2.0 * s2 * CGLB_HOT_UNITS * (c->kind == CGLB_RBF ? 1.0 : CGLB_HOT_UNITS) < 1.0e9);
+        const double oct = (c->kind == CGLB_RBF) ? 2.0 * s2 : 2.0 * std::sqrt(s2);
+        const bool int_ok = 2.0 * s2 * CGLB_HOT_UNITS * (c->kind == CGLB_RBF ? 1.0 : CGLB_HOT_UNITS) < 1.0e9;
+        // (RBF: the symmetric kernel's unweighted factor 2^(a_i + x_i.x_j) spans [-1.5 s2, 0.5 s2] octaves; fp32 exp2 range is +-126)
+        const double oct_max = (c->dtype == CGLB_F32 && c->kind == CGLB_RBF) ? 200.0 : 0.95 * CGLB_EXP_FLOOR_OCT;
+        c->exp_clamp = !(int_ok && oct < oct_max);
     }
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xh, c->xah, true));
+    CGLB_TRY(launch_hot_weights(c));
     CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zs, c->za));
     CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zh, c->zah, true));
     CGLB_TRY(launch_frag_prep(c));

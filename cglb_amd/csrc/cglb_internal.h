@@ -40,6 +40,7 @@ struct cglb_ctx {
     void* chol_blk = nullptr;            // dense copy of the current diagonal block + reciprocal diagonal (kernels_chol.hip)
     int chol_mode = 1;                   // 1: blocked LDS Cholesky (kernels_chol.hip), 0: rocSOLVER potrf
     int precond_mode = 0;                // 0: stored panel A (reference form), 1: implicit K_uf products
+    void *wh = nullptr, *pwh = nullptr;  // RBF column weights 2^(xah_j/T) and the weighted operand p_j * wh_j of the symmetric mat-vec (length N)
     void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/T octave, T = 2^CGLB_TAB_BITS (devmath.h exp2_tab)
     double* exp_tab = nullptr;           // device table 2^(k/64), k < 64
     // common terms (column-major M x M unless noted)
@@ -130,6 +131,7 @@ int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* 
 int launch_cholesky_lower(cglb_ctx* c, void* A, int* info_slot);
 int launch_frag_prep(cglb_ctx* c);
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
+int launch_hot_weights(cglb_ctx* c);  // wh = 2^(xah/T) after set_hypers (RBF)
 int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial);  // this rank's share of the global upper triangle
 int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, double* out_dl);
 int launch_kff_plain_range(cglb_ctx* c, const void* p_full, int64_t col0, int64_t col1, void* part, int64_t* nslots);

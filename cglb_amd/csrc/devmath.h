@@ -126,13 +126,23 @@ template <typename T> __device__ __forceinline__ T exp2_tab_poly(T s) {
 #endif
     return tfma_(p, s, T(1));
 }
+// The table holds 2^(k/T) with (k << (20 - BITS)) subtracted from the high word, so that ONE integer instruction
+//   hi(entry[n & (T-1)]) + (n << (20 - BITS))  =  hi(2^(k/T)) + ((n >> BITS) << 20)
+// puts the octave count straight into the exponent field (v_lshl_add_u32 instead of v_ashrrev + v_ldexp_f64).  Unlike ldexp
+// this cannot underflow gracefully: callers keep n / T inside [-1000, 1000] (range check in set_hypers or the CLAMP variant,
+// which then returns 2^-1000 ~ 1e-301 where ldexp would have returned 0).
+#define CGLB_EXP_FLOOR_OCT 1000.0
+__device__ __forceinline__ double exp2_tab_scale(double entry, int ni) {
+    const int hi = __double2hiint(entry) + (int)((unsigned)ni << (20 - CGLB_TAB_BITS));
+    return __hiloint2double(hi, __double2loint(entry));
+}
 template <bool CLAMP> __device__ __forceinline__ double exp2_tab(double xh, const double* __restrict__ tab_lds) {
-    if (CLAMP) xh = fmax(xh, -1100.0 * CGLB_TAB_SIZE);
+    if (CLAMP) xh = fmax(xh, -CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE);
     const double n = __builtin_rint(xh);
     const double s = xh - n;
     const int ni = (int)n;
     const double t = tab_lds[ni & (CGLB_TAB_SIZE - 1)];
-    return __builtin_ldexp(t * exp2_tab_poly<double>(s), ni >> CGLB_TAB_BITS);
+    return exp2_tab_scale(t, ni) * exp2_tab_poly<double>(s);
 }
 template <bool CLAMP> __device__ __forceinline__ float exp2_tab(float xh, const double* __restrict__) {
     return __builtin_amdgcn_exp2f(xh * (1.0f / (float)CGLB_TAB_SIZE));
@@ -178,12 +188,13 @@ __device__ __forceinline__ T kappa_hot_from_gram(T gram, T aj, const double* __r
 // Two-phase form of kappa_hot_from_gram for software-pipelined loops: `begin` does the range reduction and issues the
 // table read, `end` consumes it, so that a loop can start the R lookups of a column before any of them is needed.
 template <typename T> struct KappaPend { T s; T lin; int ni; T tabv; };
-template <typename T, int KIND, bool CLAMP>
+// FOLDED (RBF only): the column norm a_j is not added here - the caller has folded 2^(a_j/T) into the column operand.
+template <typename T, int KIND, bool CLAMP, bool FOLDED = false>
 __device__ __forceinline__ KappaPend<T> kappa_hot_begin(T gram, T aj, const double* __restrict__ tab) {
     KappaPend<T> k;
     T x64;
     if (KIND == CGLB_RBF) {
-        x64 = gram + aj;
+        x64 = FOLDED ? gram : gram + aj;
         k.lin = T(1);
     } else {
         const T d2 = tfma<T>(T(-2), gram, aj);
@@ -191,7 +202,11 @@ __device__ __forceinline__ KappaPend<T> kappa_hot_begin(T gram, T aj, const doub
         k.lin = tfma<T>(r, T(CGLB_LN2 / CGLB_HOT_UNITS), T(1));
         x64 = -r;
     }
-    if (CLAMP) x64 = tmax<T>(x64, T(-1100.0 * CGLB_TAB_SIZE));
+    if (sizeof(T) == 4) {  // fp32 has a hardware exp2: no table
+        k.s = x64; k.ni = 0; k.tabv = T(0);
+        return k;
+    }
+    if (CLAMP) x64 = tmax<T>(x64, T(-CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE));
     const T n = __builtin_rint(x64);
     k.s = x64 - n;
     k.ni = (int)n;
@@ -200,12 +215,15 @@ __device__ __forceinline__ KappaPend<T> kappa_hot_begin(T gram, T aj, const doub
 }
 // polynomial part (independent of the table read): overwrites k.s with P5(s) [* lin for Matern]
 template <typename T, int KIND> __device__ __forceinline__ void kappa_hot_poly(KappaPend<T>& k) {
-    T p = exp2_tab_poly<T>(k.s);
+    T p;
+    if (sizeof(T) == 4) p = (T)__builtin_amdgcn_exp2f((float)k.s * (1.0f / (float)CGLB_TAB_SIZE));
+    else p = exp2_tab_poly<T>(k.s);
     if (KIND != CGLB_RBF) p *= k.lin;
     k.s = p;
 }
 template <typename T, int KIND> __device__ __forceinline__ T kappa_hot_end(const KappaPend<T>& k) {
-    return __builtin_ldexp(k.tabv * k.s, k.ni >> CGLB_TAB_BITS);
+    if (sizeof(T) == 4) return k.s;
+    return (T)(exp2_tab_scale((double)k.tabv, k.ni) * (double)k.s);
 }
 
 // gradient factor from an exact squared distance in hot units (RBF: d2h = 64 d2s; Matern32: d2h = 4096 d2s)

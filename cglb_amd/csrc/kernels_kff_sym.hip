@@ -17,6 +17,11 @@
 //   Prow[k][i], k < nchunk : row sums of chunk k (valid for k >= first chunk of row block rb(i))
 //   Pcol[rb][j], rb < nrb  : column sums produced by row block rb (valid for rb < rb(j))
 // The diagonal 64R x 64R blocks are evaluated in full and contribute row sums only.
+//
+// Folded column norm (RBF, unclamped range): kappa_ij = 2^(a_i + x_i.x_j) * w_j with w_j = 2^(a_j), so the per-pair add of
+// a_j is dropped: the row sums use the pre-weighted operand pw_j = p_j w_j (one N-element kernel per mat-vec) and the 16
+// column sums of a batch are multiplied by w_j after the cross-lane reduction.  The unweighted factor reaches
+// 2^(|x_j|^2/2); cglb_set_hypers keeps the whole exponent range inside +-1000 octaves (fp64) / +-100 (fp32) or selects CLAMP.
 #include "devmath.h"
 #include "dispatch.h"
 
@@ -24,11 +29,14 @@
 
 template <typename T, int KIND, int DP, int R, bool CLAMP>
 __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
+                                                      const T* __restrict__ pw, const T* __restrict__ wcol,
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items, int nitems,
                                                       int rb_stride, T* __restrict__ Prow, T* __restrict__ Pcol,
                                                       const double* __restrict__ exp_tab) {
     __shared__ double tab[CGLB_TAB_SIZE];
     load_exp_table(tab, exp_tab);  // before the early exit below: every thread reaches the barrier inside
+    constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP;
+    const T* __restrict__ pc = FOLD ? pw : p;  // column-side operand
     const int lane = threadIdx.x & 63;
     // wave-uniform work item: readfirstlane makes that visible to the compiler, so everything derived from it
     // (column indices, operand addresses) lives in SGPRs and the column operands are fetched with scalar loads
@@ -60,27 +68,27 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
     const int64_t jfull = j0 + ((j1 - j0) / SYM_BATCH) * SYM_BATCH;
     // Column operands are software-pipelined one column ahead: the scalar loads of column j+1 are issued before the
     // arithmetic of column j, so their latency (and that of the table reads, which share the lgkm counter) is covered.
-    T xj[DP], aj, pj;
+    T xj[DP], aj = T(0), pj;
     if (j0 < jfull) {
         const int64_t j = row0 + j0;
-        aj = xa[j];
-        pj = p[j];
+        if (!FOLD) aj = xa[j];
+        pj = pc[j];
 #pragma unroll
         for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
     }
     for (int64_t jb = j0; jb < jfull; jb += SYM_BATCH) {
         const T* __restrict__ xsj = Xs + (row0 + jb) * DP;  // wave-uniform bases: s_load with immediate offsets
         const T* __restrict__ xaj = xa + row0 + jb;
-        const T* __restrict__ pjv = p + row0 + jb;
+        const T* __restrict__ pjv = pc + row0 + jb;
         const int64_t nb = (jb + SYM_BATCH < jfull) ? SYM_BATCH : 0;  // first column of the next batch (or a harmless re-read)
         T t[SYM_BATCH];
 #pragma unroll
         for (int jj = 0; jj < SYM_BATCH; ++jj) {
             // prefetch the next column
-            T xn[DP], an, pn;
+            T xn[DP], an = T(0), pn;
             {
                 const int64_t o = (jj + 1 < SYM_BATCH) ? jj + 1 : nb;
-                an = xaj[o];
+                if (!FOLD) an = xaj[o];
                 pn = pjv[o];
 #pragma unroll
                 for (int d = 0; d < DP; ++d) xn[d] = xsj[o * DP + d];
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
             }
             KappaPend<T> kp[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) kp[r] = kappa_hot_begin<T, KIND, CLAMP>(gram[r], aj, tab);
+            for (int r = 0; r < R; ++r) kp[r] = kappa_hot_begin<T, KIND, CLAMP, FOLD>(gram[r], aj, tab);
             __builtin_amdgcn_sched_barrier(0);  // all R table reads are in flight here ...
 #pragma unroll
             for (int r = 0; r < R; ++r) kappa_hot_poly<T, KIND>(kp[r]);
@@ -138,14 +146,14 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
             T v = t[0];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (lane < SYM_BATCH) Pcol[cslot * n + jb + lane] = v;
+            if (lane < SYM_BATCH) Pcol[cslot * n + jb + lane] = FOLD ? v * wcol[row0 + jb + lane] : v;
         }
     }
     // ragged tail of the block (fewer than 16 columns): one column at a time, plain wave reduction
     for (int64_t jc = jfull; jc < j1; ++jc) {
         const int64_t j = row0 + jc;
-        const T aj = xa[j];
-        const T pj = p[j];
+        const T aj = FOLD ? T(0) : xa[j];
+        const T pj = pc[j];
         T xj[DP];
 #pragma unroll
         for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
@@ -155,13 +163,13 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
             T gram = ai[r];
 #pragma unroll
             for (int d = 0; d < DP; ++d) gram = tfma<T>(xi[r][d], xj[d], gram);
-            const T kap = kappa_hot_from_gram<T, KIND, CLAMP>(gram, aj, tab);
+            const T kap = kappa_hot_from_gram<T, KIND, CLAMP>(gram, aj, tab);  // FOLD: aj == 0, the weight is in pj / applied below
             acc[r] = tfma<T>(kap, pj, acc[r]);
             tj = tfma<T>(kap, pr[r], tj);
         }
         if (jc >= sym_from) {
             const T v = wave_sum(tj);
-            if (lane == 0) Pcol[cslot * n + jc] = v;
+            if (lane == 0) Pcol[cslot * n + jc] = FOLD ? v * wcol[j] : v;
         }
     }
 #pragma unroll
@@ -218,6 +226,25 @@ __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restric
         const double bs = block_sum(contrib, smem);
         if (threadIdx.x == 0) dotpart[blockIdx.x] = bs;
     }
+}
+
+// wh[j] = 2^(xah[j] / T) (once per set_hypers) and pw[j] = p[j] wh[j] (once per mat-vec) for the folded column norm
+template <typename T>
+__global__ __launch_bounds__(256) void hot_weights_kernel(const T* __restrict__ xah, int64_t n, T* __restrict__ wh) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) wh[i] = exp2_neg(xah[i] * T(1.0 / CGLB_HOT_UNITS));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void weight_operand_kernel(const T* __restrict__ p, const T* __restrict__ wh, int64_t n, T* __restrict__ pw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pw[i] = p[i] * wh[i];
+}
+int launch_hot_weights(cglb_ctx* c) {
+    if (c->kind != CGLB_RBF) return CGLB_OK;
+    const int grid = (int)((c->N + 255) / 256);
+    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((hot_weights_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->xah, c->N, (T*)c->wh));
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
 }
 
 __global__ __launch_bounds__(256) void finalize_sum_sym_kernel(const double* __restrict__ partials, int n, double* __restrict__ out) {
@@ -299,12 +326,20 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     T* Pcol = Prow + (int64_t)nchunk * n;
     const int grid = (nitems + 3) / 4;
     if (grid > 0) {
-        if (c->exp_clamp)
+        if (c->exp_clamp) {
             hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full,
-                               row0, n, chunk, (const int2*)c->sym_items, nitems, world, Prow, Pcol, (const double*)c->exp_tab);
-        else
+                               (const T*)nullptr, (const T*)nullptr, row0, n, chunk, (const int2*)c->sym_items, nitems, world, Prow, Pcol,
+                               (const double*)c->exp_tab);
+        } else {
+            if (KIND == CGLB_RBF) {  // folded column norm: pre-weight the operand over the columns of this block
+                hipLaunchKernelGGL((weight_operand_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, p_full + row0,
+                                   (const T*)c->wh + row0, n, (T*)c->pwh + row0);
+                CGLB_LAUNCH_CHECK(c);
+            }
             hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full,
-                               row0, n, chunk, (const int2*)c->sym_items, nitems, world, Prow, Pcol, (const double*)c->exp_tab);
+                               (const T*)c->pwh, (const T*)c->wh, row0, n, chunk, (const int2*)c->sym_items, nitems, world, Prow, Pcol,
+                               (const double*)c->exp_tab);
+        }
         CGLB_LAUNCH_CHECK(c);
     }
     if (c->kff_skip_combine) return CGLB_OK;

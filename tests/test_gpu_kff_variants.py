@@ -86,3 +86,29 @@ def test_cyclic_partials_sum_to_full_matvec(N, world):
         _lib.check(ctx.lib.cglb_matvec_cyclic(ctx._ctx, c_void_p(p.data_ptr()), c_void_p(out.data_ptr())), ctx._ctx)
         total += out.cpu().numpy()
     np.testing.assert_allclose(total, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("half_width", [12.3, 12.7, 40.0])
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+def test_symmetric_matvec_at_the_exponent_range_limit(kind, half_width):
+    """The symmetric RBF kernel folds 2^(a_j) into the column operand, so its unweighted factor spans up to +-1000 octaves;
+    cglb_set_hypers switches to the clamped variant beyond 0.95 of that.  12.3 / 12.7 straddle the switch for D=2, l=1
+    (2 |x|^2 log2(e) = 950 octaves at 12.83 -> with the data's own max), 40 is far inside the clamped regime."""
+    from cglb_amd.hip_context import HipContext
+    N, D = 1500, 2
+    rng = np.random.default_rng(11)
+    X = rng.uniform(-half_width, half_width, size=(N, D))
+    X[0] = [half_width, half_width]
+    X[1] = [-half_width, -half_width]
+    X[2] = [half_width, -half_width]
+    X[3] = X[0] * (1 - 1e-9)  # near-duplicate of the farthest point: largest unweighted factor times smallest weight
+    y = rng.standard_normal(N)
+    Z = X[:8].copy()
+    hyp = orc.Hypers(np.ones(D), 1.3, 0.2, 0.0, Z, 1e-6)
+    ctx = HipContext(X, y, 8, kind)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, 1e-6)
+    p = rng.standard_normal(N)
+    out = ctx.matvec(torch.from_numpy(p)).cpu().numpy()
+    ref = orcc.kff_matvec(kind, X, hyp, p)
+    assert np.isfinite(out).all()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10 * np.abs(ref).max())

@@ -107,11 +107,13 @@ def test_world1_cyclic_driver_equals_fused_path(name):
     drv = SymShardedCGLB(HipSymLocalOps(ctx2))
     drv.v.copy_(torch.from_numpy(g["v0"]).to(ctx2.device))
     res = drv.objective_and_grad(True, *args)
-    assert res.steps == fused.steps
     if fused.steps > 40:
-        # long solve: the two drivers sum r^T z in different orders and CG amplifies that round-off (see test_oracle_golden)
-        assert res.bound == pytest.approx(fused.bound, rel=1e-8)
+        # long solve: the two drivers sum r^T z in different orders and CG amplifies that round-off (see test_oracle_golden):
+        # the stop test may flip one iteration earlier or later
+        assert abs(res.steps - fused.steps) <= 1
+        assert res.bound == pytest.approx(fused.bound, rel=1e-7)
         return
+    assert res.steps == fused.steps
     assert res.bound == pytest.approx(fused.bound, rel=1e-11)
     D = g["X"].shape[1]
     np.testing.assert_allclose(res.grad[:D], fused.grad["lengthscales"], rtol=1e-9, atol=1e-10)
