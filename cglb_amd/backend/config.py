@@ -80,6 +80,11 @@ Matern32Config = _record("Matern32Config", (SquaredExponentialConfig,), doc="ARD
 
 
 def _inducing_init(self, data: Data, kernel_fn: Callable):
+    # A kernel callback may bring its own device implementation of the same selection rule (the hip backend does:
+    # cglb_select_inducing); a plain callable goes through the generic numpy form above.
+    accelerated = getattr(kernel_fn, "select_inducing", None)
+    if accelerated is not None:
+        return accelerated(np.asarray(data[0]), self.num_variables)
     return greedy_conditional_variance(np.asarray(data[0]), self.num_variables, kernel_fn)
 
 

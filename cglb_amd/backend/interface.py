@@ -143,6 +143,28 @@ def _kernel_numpy(kernel: ScaleKernel, x1, x2, full_cov: bool):
     return var * (1.0 + np.sqrt(3.0) * r) * np.exp(-np.sqrt(3.0) * r)
 
 
+class _InitKernel:
+    """The init_kernel_fn callback of interface.py:278-284, plus the HIP implementation of the greedy selection it feeds
+    (config.py:62-65 -> cglb_select_inducing): the O(N M^2) pivoted Cholesky runs on the GPU, not through this callback."""
+
+    def __init__(self, kernel: ScaleKernel):
+        self.kernel = kernel
+
+    def __call__(self, x1, x2=None, full_cov: bool = False):
+        return _kernel_numpy(self.kernel, x1, x2, full_cov)
+
+    def select_inducing(self, X: np.ndarray, num_variables: int) -> np.ndarray:
+        from ..hip_context import HipContext
+        X = np.asarray(X, dtype=np.float64).reshape(len(X), -1)
+        ctx = HipContext(X, np.zeros(X.shape[0]), num_variables, self.kernel.base_kernel.kind, dtype=_STATE["dtype"])
+        try:
+            ls = _numpy(self.kernel.base_kernel.lengthscale).reshape(-1)
+            indices, _ = ctx.select_inducing(ls, float(self.kernel.outputscale.detach()))
+        finally:
+            ctx.close()
+        return X[indices].copy()
+
+
 def _likelihood_and_kernel_for_sgpr(model_cfg: SGPRConfig, data: Data):
     """interface.py:263-301"""
     params = model_cfg.params(data)
@@ -150,10 +172,7 @@ def _likelihood_and_kernel_for_sgpr(model_cfg: SGPRConfig, data: Data):
     likelihood.noise = params["noise_variance"]
     base_kernel = create_kernel(model_cfg.kernel, data)
 
-    def init_kernel_fn(x1, x2=None, full_cov: bool = False):
-        return _kernel_numpy(base_kernel, x1, x2, full_cov)
-
-    inducing_variable = params["inducing_variable"](init_kernel_fn)
+    inducing_variable = params["inducing_variable"](_InitKernel(base_kernel))
     return likelihood, InducingPointKernel(base_kernel, inducing_variable)
 
 

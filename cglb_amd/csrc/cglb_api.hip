@@ -796,6 +796,43 @@ int cglb_objective_and_grad(cglb_ctx* c, void* v_inout, int run_cg, double max_e
     return obj_finish(c, sc, out4);
 }
 
+// ---- inducing-point initialisation (config.py:55-65; kernels_select.hip) -------------------------------------------
+int cglb_select_inducing(cglb_ctx* c, const double* lengthscales, double variance, double jitter, int64_t* indices_out, void* Z_out,
+                         double* trace_out) {
+    if (!c || !lengthscales || !indices_out) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    if (!c->have_data) return cglb_fail(c, CGLB_ERR_STATE, "set_data must precede select_inducing");
+    if (!(variance > 0) || !(jitter >= 0)) return cglb_fail(c, CGLB_ERR_BAD_ARG, "variance must be positive, jitter >= 0");
+    for (int d = 0; d < c->D; ++d)
+        if (!(lengthscales[d] > 0) || !std::isfinite(lengthscales[d])) return cglb_fail(c, CGLB_ERR_BAD_ARG, "lengthscales must be positive");
+    HIP_CHECK(c, hipSetDevice(c->device));
+    // the scaled operand buffers of the context serve as scratch: whatever set_hypers had put there is invalidated
+    double saved[CGLB_MAX_D];
+    for (int d = 0; d < c->D; ++d) { saved[d] = c->ls[d]; c->ls[d] = lengthscales[d]; }
+    const int rc_prep = launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa);
+    for (int d = 0; d < c->D; ++d) c->ls[d] = saved[d];
+    c->have_hypers = c->have_local = c->have_terms = false;
+    if (rc_prep != CGLB_OK) return rc_prep;
+    const int M = (int)(c->M < c->N ? c->M : c->N);
+    long long* chosen_dev = nullptr;
+    double* trace_dev = nullptr;
+    HIP_CHECK(c, hipMalloc(&chosen_dev, (size_t)M * sizeof(long long)));
+    hipError_t e = hipMalloc(&trace_dev, sizeof(double));
+    if (e != hipSuccess) { (void)hipFree(chosen_dev); return cglb_fail(c, CGLB_ERR_HIP, hipGetErrorString(e)); }
+    int rc = launch_select_inducing(c, variance, jitter, chosen_dev, Z_out, trace_dev);
+    if (rc == CGLB_OK) {
+        std::vector<long long> host(M);
+        e = hipMemcpy(host.data(), chosen_dev, (size_t)M * sizeof(long long), hipMemcpyDeviceToHost);
+        double tr = 0.0;
+        if (e == hipSuccess) e = hipMemcpy(&tr, trace_dev, sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = cglb_fail(c, CGLB_ERR_HIP, hipGetErrorString(e));
+        for (int m = 0; m < M; ++m) indices_out[m] = (int64_t)host[m];
+        if (trace_out) *trace_out = tr;
+    }
+    (void)hipFree(chosen_dev);
+    (void)hipFree(trace_dev);
+    return rc;
+}
+
 int cglb_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var) {
     if (!c || !v_full || !xnew || !f_mean || !f_var || n_new < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
     CGLB_TRY(require_single(c));

@@ -124,6 +124,7 @@ static inline int pad_dim(int d) {
 // kernels_prep.hip
 int launch_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out, bool hot = false);
 double cglb_hot_scale(const cglb_ctx* c);  // xh = hot_scale * xs
+int launch_select_inducing(cglb_ctx* c, double variance, double jitter, long long* chosen_dev, void* Z_out, double* trace_dev);  // kernels_select.hip
 int launch_kuf(cglb_ctx* c);  // At <- Kuf[:, rows] (unscaled by sigma)
 int launch_kuu(cglb_ctx* c);  // Lc <- Kuu + jitter I (full symmetric)
 // kernels_kff.hip

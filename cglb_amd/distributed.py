@@ -353,8 +353,14 @@ class SymShardedCGLB:
         ops, N = self.ops, self.N
         zf = self.zbuf[:N]
         ops.rhs_full(self.b)
-        self.matvec(self.v, self.Kv)                               # :57
-        ops.vec_residual(N, self.r, self.b, self.Kv)               # :58
+        ops.vec_dot(N, self.v, self.v, self.scratch)
+        if float(self.scratch.item()) == 0.0:
+            # cold start (models.py:59-68): A v == 0 and r == b exactly, so the mat-vec and its all-reduce are skipped
+            # (bit-identical; v is replicated, every rank takes the same branch) - same rule as the fused pcg_impl
+            self.r.copy_(self.b)
+        else:
+            self.matvec(self.v, self.Kv)                           # :57
+            ops.vec_residual(N, self.r, self.b, self.Kv)           # :58
         self._precond(self.rz)                                     # :59
         ops.vec_update_p(N, self.p, zf, self.rz, self.rz, True)    # :61
         rz = float(self.rz.item())

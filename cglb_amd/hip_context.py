@@ -176,6 +176,20 @@ class HipContext:
         return {"lengthscales": g[:D].copy(), "variance": float(g[D]), "noise": float(g[D + 1]), "mean": float(g[D + 2]),
                 "Z": g[D + 3:].reshape(M, D).copy()}
 
+    def select_inducing(self, lengthscales, variance, jitter=1e-12, return_Z=False):
+        """Greedy conditional-variance choice of the M inducing points under the given (initial) kernel - config.py:55-65.
+        Returns (indices int64 [min(M, N)], remaining trace) and, if asked, the device tensor Z = X[indices].
+        Must be followed by set_hypers before any other call."""
+        ls = np.ascontiguousarray(np.broadcast_to(np.asarray(lengthscales, dtype=np.float64).reshape(-1), (self.D,)))
+        msel = min(self.M, self.N)
+        idx = np.empty(msel, dtype=np.int64)
+        Z = torch.empty((msel, self.D), dtype=self.dtype, device=self.device) if return_Z else None
+        trace = c_double()
+        rc = self.lib.cglb_select_inducing(self._ctx, ls.ctypes.data_as(ctypes.POINTER(c_double)), float(variance), float(jitter),
+                                           idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _ptr(Z), byref(trace))
+        _lib.check(rc, self._ctx)
+        return (idx, trace.value, Z) if return_Z else (idx, trace.value)
+
     def predict(self, v_full, xnew) -> Tuple[torch.Tensor, torch.Tensor]:
         xn = torch.as_tensor(xnew, dtype=self.dtype).reshape(-1, self.D).contiguous().to(self.device)
         v = self._dev(v_full, self.N)

@@ -156,6 +156,16 @@ int cglb_shard_obj_phase3_cyclic(cglb_ctx* ctx, const void* v_full, const void* 
 /* f_mean, f_var: dev [n_new].  v_full: dev [n] solution at tolerance 1e-3 (models.py:291). single shard. */
 int cglb_predict(cglb_ctx* ctx, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var);
 
+/* ---- inducing-point initialisation: InducingVariableConfig.init, config.py:55-65 ------------------------
+ * The reference calls robustgp.ConditionalVariance(sample=False) (third-party): greedy maximisation of the conditional
+ * variance under the INITIAL kernel (pivoted Cholesky of K_ff, lowest index on ties).  Needs set_data only; works on all n rows
+ * whatever the row range of the context, so every rank of a sharded run obtains the same answer.  `lengthscales` host [d];
+ * indices_out: host [min(m, n)] row indices in selection order; Z_out: dev [m, d] = X[indices] or NULL; trace_out: host,
+ * sum of the remaining conditional variances, tr(K_ff - Q_ff) (+ n * jitter), or NULL.  Invalidates set_hypers (the scaled
+ * operand buffers are used as scratch).  Blocking. */
+int cglb_select_inducing(cglb_ctx* ctx, const double* lengthscales, double variance, double jitter, int64_t* indices_out, void* Z_out,
+                         double* trace_out);
+
 /* ---- introspection / measurement ------------------------------------------------------------------ */
 /* Copy common-term matrices out (tests): which = 0:A [m,n_local] 1:L [m,m] lower 2:LB [m,m] lower; dst: any. */
 int cglb_get_matrix(cglb_ctx* ctx, int which, void* dst);
