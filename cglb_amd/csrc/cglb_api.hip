@@ -297,9 +297,14 @@ int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter
     HIP_CHECK(c, hipMemcpyAsync(c->w_p, c->w_z, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
     double rz = 0;
     CGLB_TRY(read_scalars(c, S + S_RZ, &rz, 1));
+    // The stop predicate (:65) is evaluated on the host, like the reference's (:80-81).  Look-ahead: while the residual is
+    // still far above the tolerance (more than 4x after the PREVIOUS iteration), the mat-vec of the next iteration is enqueued
+    // before the host waits for this iteration's scalar, so the GPU does not idle over the read-back.  If the predicate then
+    // says stop, that mat-vec was wasted (it only writes Ap and the p.Ap slot): results are identical either way.
     int i = 0;
+    bool ahead = false;
     while (0.5 * rz > max_error && i < max_iter) {  // :65
-        CGLB_TRY(launch_kff_matvec(c, c->w_p, c->w_Ap, S + S_PAP));                                // :66 and (p*Ap).sum()
+        if (!ahead) CGLB_TRY(launch_kff_matvec(c, c->w_p, c->w_Ap, S + S_PAP));                    // :66 and (p*Ap).sum()
         const int restart = (restart_iter > 0) && (i % restart_iter == restart_iter - 1);          // :70
         CGLB_TRY(launch_update_v_r(c, v, c->w_r, c->w_p, c->w_Ap, S + S_RZ, S + S_PAP, !restart));  // :67-68, :72
         if (restart) {
@@ -309,7 +314,12 @@ int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter
         CGLB_TRY(precond_single(c, c->w_r, c->w_z, S + S_NRZ));                                     // :73
         CGLB_TRY(launch_update_p(c, c->w_p, c->w_z, S + S_NRZ, S + S_RZ, restart));                 // :75
         HIP_CHECK(c, hipMemcpyAsync(S + S_RZ, S + S_NRZ, sizeof(double), hipMemcpyDeviceToDevice, c->stream));  // :76
-        CGLB_TRY(read_scalars(c, S + S_NRZ, &rz, 1));                                               // host test of :65 (and the sync of :80-81)
+        HIP_CHECK(c, hipMemcpyAsync(c->host_scal, S + S_NRZ, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(c, hipEventRecord(c->scal_event, c->stream));
+        ahead = c->pcg_lookahead && (i + 1 < max_iter) && (0.5 * rz > 4.0 * max_error);  // rz: still the value of the previous iteration
+        if (ahead) CGLB_TRY(launch_kff_matvec(c, c->w_p, c->w_Ap, S + S_PAP));
+        HIP_CHECK(c, hipEventSynchronize(c->scal_event));                                            // host test of :65 (and the sync of :80-81)
+        rz = c->host_scal[0];
         ++i;
     }
     if (steps) *steps = i;
@@ -474,6 +484,11 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     CR(dalloc(c, (void**)&c->scal, 64 * sizeof(double)));
     CR(dalloc(c, (void**)&c->gradbuf, (size_t)CGLB_GRAD_LEN(d, m) * sizeof(double)));
     { hipError_t e2 = hipMemsetAsync(c->scal, 0, 64 * sizeof(double), c->stream); if (e2 != hipSuccess) { c->err = "memset failed"; return fail(CGLB_ERR_HIP); } }
+    {
+        hipError_t e4 = hipHostMalloc((void**)&c->host_scal, 8 * sizeof(double), hipHostMallocDefault);
+        if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&c->scal_event, hipEventDisableTiming);
+        if (e4 != hipSuccess) { c->err = std::string("pinned scalar buffer: ") + hipGetErrorString(e4); return fail(CGLB_ERR_HIP); }
+    }
 #undef CR
     *out = c;
     return CGLB_OK;
@@ -487,6 +502,8 @@ int cglb_ctx_destroy(cglb_ctx* c) {
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
                     c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->host_scal) (void)hipHostFree(c->host_scal);
+    if (c->scal_event) (void)hipEventDestroy(c->scal_event);
     if (c->blas) (void)rocblas_destroy_handle(c->blas);
     delete c;
     return CGLB_OK;
@@ -498,6 +515,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "kff_jsplit")) c->kff_jsplit = (int)value;
     else if (!strcmp(name, "kff_rows")) c->kff_rows = (int)value;
     else if (!strcmp(name, "sym_chunk")) c->sym_chunk_opt = value;
+    else if (!strcmp(name, "pcg_lookahead")) c->pcg_lookahead = (int)value;
     else if (!strcmp(name, "chol_mode")) c->chol_mode = (int)value;
     else if (!strcmp(name, "precond_mode")) { c->precond_mode = (int)value; c->have_local = c->have_terms = false; }
     else return cglb_fail(c, CGLB_ERR_BAD_ARG, std::string("unknown option ") + name);

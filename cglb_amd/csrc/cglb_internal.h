@@ -72,6 +72,9 @@ struct cglb_ctx {
     void* tpart = nullptr;         // A^T t partial sums [msplit][nloc]
     double* dotpart = nullptr;     // block partials for dots (double always) [DOTPART_CAP]
     double* scal = nullptr;        // device scalars (double) [64]
+    double* host_scal = nullptr;   // pinned host mirror for the asynchronous read of the stop-test scalar
+    hipEvent_t scal_event = nullptr;
+    int pcg_lookahead = 1;         // 1: enqueue the next mat-vec before waiting for the stop-test scalar (pcg_impl)
     double* gpart = nullptr;       // gradient partial buffers
     size_t gpart_cap = 0;
     double* gradbuf = nullptr;     // device packed gradient [GRAD_LEN]

@@ -319,9 +319,28 @@ class SymShardedCGLB:
         self.sc = z(8, torch.float64)
         self.grad = z(self.D + 3 + self.M * self.D, torch.float64)
         ops.set_parallel(G, self.comm.rank)
+        self.lookahead = True
+        self._pinned = None
+        self._event = None
 
     def _own(self, buf):
         return buf[self.comm.rank * self.per: self.comm.rank * self.per + self.nloc]
+
+    def _read_scalar_async(self, t):
+        """Starts the device->host copy of a 1-element tensor; the returned callable waits for it and gives the float."""
+        if t.device.type != "cuda":
+            value = float(t.item())
+            return lambda: value
+        if self._pinned is None:
+            self._pinned = torch.empty(1, dtype=torch.float64).pin_memory()
+            self._event = torch.cuda.Event()
+        self._pinned.copy_(t, non_blocking=True)
+        self._event.record(torch.cuda.current_stream(t.device))
+
+        def wait():
+            self._event.synchronize()
+            return float(self._pinned[0])
+        return wait
 
     def v_full(self):
         return self.v
@@ -365,8 +384,10 @@ class SymShardedCGLB:
         ops.vec_update_p(N, self.p, zf, self.rz, self.rz, True)    # :61
         rz = float(self.rz.item())
         i = 0
+        ahead = False
         while 0.5 * rz > max_error and i < max_cg_iter:            # :65
-            self.matvec(self.p, self.Ap)                           # :66
+            if not ahead:
+                self.matvec(self.p, self.Ap)                       # :66
             ops.vec_dot(N, self.p, self.Ap, self.pAp)              # :67
             restart = restart_cg_iter > 0 and (i % restart_cg_iter == restart_cg_iter - 1)  # :70
             ops.vec_update_v_r(N, self.v, self.r, self.p, self.Ap, self.rz, self.pAp, not restart)  # :68, :72
@@ -376,7 +397,14 @@ class SymShardedCGLB:
             self._precond(self.rz_new)                             # :73
             ops.vec_update_p(N, self.p, zf, self.rz_new, self.rz, restart)  # :75
             self.rz.copy_(self.rz_new)                             # :76
-            rz = float(self.rz.item())
+            # Host test of :65 with look-ahead (same rule as the fused pcg_impl): while the residual is still far above the
+            # tolerance the next mat-vec (kernel + all-reduce) is enqueued before the host waits for this iteration's scalar;
+            # if the test then says stop it was wasted work on Ap only.  rz is identical on all ranks -> same decision everywhere.
+            pending = self._read_scalar_async(self.rz)
+            ahead = self.lookahead and (i + 1 < max_cg_iter) and (0.5 * rz > 4.0 * max_error)
+            if ahead:
+                self.matvec(self.p, self.Ap)
+            rz = pending()
             i += 1
         return i, 0.5 * rz
 

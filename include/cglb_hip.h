@@ -173,7 +173,8 @@ int cglb_get_matrix(cglb_ctx* ctx, int which, void* dst);
  * which = 0: K_ff mat-vec (pair kernel + slab combine), 1: preconditioner apply, 2: gradient bilinear pass,
  * 3: the pair kernel of the mat-vec alone (the dominant kernel), 4: the same for this rank's cyclic share (cglb_set_parallel). */
 int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
-/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" ...; returns CGLB_ERR_BAD_ARG if unknown. */
+/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" ...;
+ * returns CGLB_ERR_BAD_ARG if unknown. */
 int cglb_set_option(cglb_ctx* ctx, const char* name, int64_t value);
 
 #ifdef __cplusplus

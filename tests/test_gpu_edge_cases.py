@@ -91,3 +91,25 @@ def test_warm_start_is_not_mutated_by_solver_and_reused_by_objective():
     assert s2 == 0 and torch.equal(v2, v1)                                        # already converged: predicate fails before any step
     res = ctx.objective_and_grad(v1.clone(), True, 1.0, with_grad=False)
     assert res.steps == 0
+
+
+@pytest.mark.parametrize("name,max_error", [("rbf_d8_trained", 1.0), ("rbf_d8_init", 1.0), ("rbf_d8_restart", None), ("rbf_d8_init", 50.0)])
+def test_lookahead_stop_test_does_not_change_results(name, max_error):
+    """pcg_lookahead=1 enqueues the next mat-vec before the host has seen the stop-test scalar; a wasted speculative mat-vec
+    (residual dropping by more than 4x in one iteration - the well-conditioned init case with a loose tolerance) must leave
+    v, steps and the residual bitwise unchanged."""
+    from conftest import load_golden
+    from cglb_amd.hip_context import HipContext
+    g = load_golden(name)
+    me = float(g["max_error"]) if max_error is None else max_error
+    outs = []
+    for la in (0, 1):
+        ctx = HipContext(g["X"], g["y"], g["Z"].shape[0], int(g["kind"]))
+        ctx.set_option("pcg_lookahead", la)
+        ctx.set_hypers(g["lengthscales"], float(g["variance"]), float(g["noise"]), float(g["mean"]), g["Z"], float(g["jitter"]))
+        ctx.setup()
+        b = torch.from_numpy(g["y"] - float(g["mean"]))
+        v, steps, half = ctx.pcg(b, torch.from_numpy(g["v0"]), me, int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+        outs.append((v.cpu().numpy(), steps, half))
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    assert np.array_equal(outs[0][0], outs[1][0])
