@@ -293,10 +293,11 @@ int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter
         CGLB_TRY(launch_kff_matvec(c, v, c->w_Kv, nullptr));
         CGLB_TRY(launch_residual(c, c->w_r, b, c->w_Kv));
     }
-    CGLB_TRY(precond_single(c, c->w_r, c->w_z, S + S_RZ));
+    double *s_rz = S + S_RZ, *s_nrz = S + S_NRZ;  // the two slots swap roles every iteration (:76) instead of being copied
+    CGLB_TRY(precond_single(c, c->w_r, c->w_z, s_rz));
     HIP_CHECK(c, hipMemcpyAsync(c->w_p, c->w_z, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
     double rz = 0;
-    CGLB_TRY(read_scalars(c, S + S_RZ, &rz, 1));
+    CGLB_TRY(read_scalars(c, s_rz, &rz, 1));
     // The stop predicate (:65) is evaluated on the host, like the reference's (:80-81).  Look-ahead: while the residual is
     // still far above the tolerance (more than 4x after the PREVIOUS iteration), the mat-vec of the next iteration is enqueued
     // before the host waits for this iteration's scalar, so the GPU does not idle over the read-back.  If the predicate then
@@ -306,15 +307,15 @@ int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter
     while (0.5 * rz > max_error && i < max_iter) {  // :65
         if (!ahead) CGLB_TRY(launch_kff_matvec(c, c->w_p, c->w_Ap, S + S_PAP));                    // :66 and (p*Ap).sum()
         const int restart = (restart_iter > 0) && (i % restart_iter == restart_iter - 1);          // :70
-        CGLB_TRY(launch_update_v_r(c, v, c->w_r, c->w_p, c->w_Ap, S + S_RZ, S + S_PAP, !restart));  // :67-68, :72
+        CGLB_TRY(launch_update_v_r(c, v, c->w_r, c->w_p, c->w_Ap, s_rz, S + S_PAP, !restart));  // :67-68, :72
         if (restart) {
             CGLB_TRY(launch_kff_matvec(c, v, c->w_Kv, nullptr));
             CGLB_TRY(launch_residual(c, c->w_r, b, c->w_Kv));
         }
-        CGLB_TRY(precond_single(c, c->w_r, c->w_z, S + S_NRZ));                                     // :73
-        CGLB_TRY(launch_update_p(c, c->w_p, c->w_z, S + S_NRZ, S + S_RZ, restart));                 // :75
-        HIP_CHECK(c, hipMemcpyAsync(S + S_RZ, S + S_NRZ, sizeof(double), hipMemcpyDeviceToDevice, c->stream));  // :76
-        HIP_CHECK(c, hipMemcpyAsync(c->host_scal, S + S_NRZ, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        CGLB_TRY(precond_single(c, c->w_r, c->w_z, s_nrz));                                         // :73
+        CGLB_TRY(launch_update_p(c, c->w_p, c->w_z, s_nrz, s_rz, restart));                         // :75
+        std::swap(s_rz, s_nrz);                                                                     // :76
+        HIP_CHECK(c, hipMemcpyAsync(c->host_scal, s_rz, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(c, hipEventRecord(c->scal_event, c->stream));
         ahead = c->pcg_lookahead && (i + 1 < max_iter) && (0.5 * rz > 4.0 * max_error);  // rz: still the value of the previous iteration
         if (ahead) CGLB_TRY(launch_kff_matvec(c, c->w_p, c->w_Ap, S + S_PAP));

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
 
 // out[i] = var * ( sum_s plain[s][i] + sum_{k >= k0(i)} Prow[k][i] + sum_{rb < rb(i)} Pcol[rb][i] ) + noise * pdiag[i]
 // With a cyclic distribution (world > 1) only the row blocks rb == rank (mod world) were processed here: row sums exist for
-// the rows of those blocks, column sums come from those blocks only, and the noise term is left to the caller (pdiag == null).
+// the rows of those blocks, column sums come from those blocks only, and only rank 0 adds the noise term (pdiag == null elsewhere).
 template <typename T>
 __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restrict__ plain, int nplain, const T* __restrict__ Prow, int nchunk,
                                                               const T* __restrict__ Pcol, int64_t n, int64_t chunk, int rbrows, int world, int rank,
@@ -284,7 +284,7 @@ static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, i
 
 // cyclic == false: the square block of the local row shard [r0, r1) plus plain kernels for the off-diagonal ranges.
 // cyclic == true : the whole N x N upper triangle, row blocks rb == par_rank (mod par_world); output is a full-N PARTIAL vector
-//                  (var * sums, no noise term) that the caller all-reduces.
+//                  (var * sums; rank 0 adds the noise term noise * p) that the caller all-reduces into (K_ff + noise I) p.
 template <typename T, int KIND, int DP>
 static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* pdot_slot, bool cyclic) {
     constexpr int R = (DP <= 8) ? 4 : (DP <= 16 ? 2 : 1);
@@ -346,7 +346,7 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     const int cgrid = (int)((n + 255) / 256);
     if (pdot_slot && cgrid > DOTPART_CAP) return cglb_fail(c, CGLB_ERR_BAD_ARG, "row shard too large for dot partials");
     hipLaunchKernelGGL((kff_sym_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)plain, (int)nplain, (const T*)Prow, nchunk,
-                       (const T*)Pcol, n, chunk, RBROWS, world, rank, (T)c->var, (T)c->noise, cyclic ? (const T*)nullptr : p_full + c->r0, out_local,
+                       (const T*)Pcol, n, chunk, RBROWS, world, rank, (T)c->var, (T)c->noise, cyclic ? (rank == 0 ? p_full : (const T*)nullptr) : p_full + c->r0, out_local,
                        pdot_slot ? c->dotpart : nullptr);
     CGLB_LAUNCH_CHECK(c);
     if (pdot_slot) {

@@ -54,6 +54,10 @@ class Comm:
         if self.world == 1 and not self.force:
             return
         mine = buf[self.rank * per:(self.rank + 1) * per]
+        if buf.is_cuda:
+            # RCCL's in-place form: the send buffer is this rank's slot of the receive buffer (no staging copy)
+            dist.all_gather_into_tensor(buf, mine, group=self.group)
+            return
         try:
             dist.all_gather_into_tensor(buf, mine.clone(), group=self.group)
         except (RuntimeError, NotImplementedError):
@@ -353,9 +357,8 @@ class SymShardedCGLB:
 
     def matvec(self, x_full, out_full):
         """out = (K_ff + noise I) x, full length on every rank."""
-        self.ops.matvec_cyclic(x_full, out_full)
+        self.ops.matvec_cyclic(x_full, out_full)    # rank 0's partial carries the noise term
         self.comm.allreduce(out_full)
-        self.ops.vec_axpy(self.N, self.ops.noise, x_full, out_full)
 
     def _precond(self, rz_out):
         """z = P r (full, gathered into zbuf[:N]); rz_out = r^T z."""
@@ -396,7 +399,7 @@ class SymShardedCGLB:
                 ops.vec_residual(N, self.r, self.b, self.Kv)
             self._precond(self.rz_new)                             # :73
             ops.vec_update_p(N, self.p, zf, self.rz_new, self.rz, restart)  # :75
-            self.rz.copy_(self.rz_new)                             # :76
+            self.rz, self.rz_new = self.rz_new, self.rz            # :76 (the two scalar slots swap roles: no copy kernel)
             # Host test of :65 with look-ahead (same rule as the fused pcg_impl): while the residual is still far above the
             # tolerance the next mat-vec (kernel + all-reduce) is enqueued before the host waits for this iteration's scalar;
             # if the test then says stop it was wasted work on Ap only.  rz is identical on all ranks -> same decision everywhere.

@@ -134,7 +134,8 @@ int cglb_shard_obj_finish(cglb_ctx* ctx, const void* sc /* dev double[8], reduce
 /* ---- cyclic-symmetric multi-GPU path ----------------------------------------------------------------------------
  * K_ff is symmetric, and the symmetric pair kernel (each kappa_ij used for out_i and out_j) halves the work of a mat-vec.
  * To keep that factor under sharding the GLOBAL upper triangle is dealt to the ranks by cyclic 256-row blocks:
- * cglb_matvec_cyclic produces this rank's full-length PARTIAL K_ff p (no noise term); the host all-reduces it and every
+ * cglb_matvec_cyclic produces this rank's full-length PARTIAL of (K_ff + noise I) p (the noise term is added by rank 0 only);
+ * the host all-reduces it and every
  * rank holds the full vectors p, Ap, v, r (their updates are O(N) and done redundantly with the cglb_vec_* primitives).
  * Only the Nystrom panel stays column-sharded (rows [row_begin,row_end)): u = A r is all-reduced (M), z is all-gathered. */
 int cglb_set_parallel(cglb_ctx* ctx, int world, int rank);

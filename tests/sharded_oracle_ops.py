@@ -166,6 +166,8 @@ class OracleSymLocalOps(OracleLocalOps, SymLocalOps):
             res[a:b] += self.Kfull[a:b, a:] @ p[a:]          # rows of the block against columns >= its first row
             if b < self.N:
                 res[b:] += self.Kfull[a:b, b:].T @ p[a:b]    # transposed use of the strictly-right part
+        if self.rank == 0:
+            res += self.hyp.noise * p                        # the noise term travels with rank 0's partial
         out.copy_(torch.from_numpy(res))
 
     def vec_dot(self, n, a, b, out): out[0] = float(a.numpy()[:n] @ b.numpy()[:n])
