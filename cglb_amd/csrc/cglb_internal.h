@@ -85,7 +85,7 @@ struct cglb_ctx {
     std::string err;
 };
 
-#define DOTPART_CAP 8192
+#define DOTPART_CAP 65536
 
 #define HIP_CHECK(ctx, expr)                                                                         \
     do {                                                                                             \

@@ -182,39 +182,46 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
 // out[i] = var * ( sum_s plain[s][i] + sum_{k >= k0(i)} Prow[k][i] + sum_{rb < rb(i)} Pcol[rb][i] ) + noise * pdiag[i]
 // With a cyclic distribution (world > 1) only the row blocks rb == rank (mod world) were processed here: row sums exist for
 // the rows of those blocks, column sums come from those blocks only, and only rank 0 adds the noise term (pdiag == null elsewhere).
+// Block = 64 elements x 4 slot groups: wave g adds the slots g, g+4, g+8, ... of each of the three slab lists (8 loads in flight
+// per lane, slab rows are n elements apart), the four group sums are added in fixed order through LDS -> bitwise reproducible.
+// (One thread per element left a rank of a cyclic run with ~400 dependent slab reads on 1/world of its threads: 46 us at world 8.)
 template <typename T>
 __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restrict__ plain, int nplain, const T* __restrict__ Prow, int nchunk,
                                                               const T* __restrict__ Pcol, int64_t n, int64_t chunk, int rbrows, int world, int rank,
                                                               T var, T noise, const T* __restrict__ pdiag, T* __restrict__ out,
                                                               double* __restrict__ dotpart) {
     __shared__ double smem[16];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ T gsum[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     double contrib = 0.0;
+    T a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (i < n) {
-        // slot sums with 8 independent accumulators: the slab rows are n elements apart, so a single running sum would
-        // serialise ~300 dependent loads per element; the order is still fixed (bitwise reproducible)
-        T a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int q = 0; q < nplain; ++q) a[q & 7] += plain[(int64_t)q * n + i];
+        for (int q = g, u = 0; q < nplain; q += 4, u = (u + 1) & 7) a[u] += plain[(int64_t)q * n + i];
         const int64_t rbi = i / rbrows;
         if (rbi % world == rank) {
             const int64_t k0 = (rbi * rbrows) / chunk;
-            int64_t k = k0;
-            for (; k + 8 <= nchunk; k += 8) {
+            int64_t k = k0 + g;
+            for (; k + 28 < nchunk; k += 32) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] += Prow[(k + u) * n + i];
+                for (int u = 0; u < 8; ++u) a[u] += Prow[(k + 4 * u) * n + i];
             }
-            for (int u = 0; k < nchunk; ++k, ++u) a[u] += Prow[k * n + i];
+            for (int u = 0; k < nchunk; k += 4, ++u) a[u] += Prow[k * n + i];
         }
         {
             const int64_t ns = rbi > rank ? (rbi - rank + world - 1) / world : 0;  // column-sum slots 0 .. ns-1 are valid for this element
-            int64_t c = 0;
-            for (; c + 8 <= ns; c += 8) {
+            int64_t c = g;
+            for (; c + 28 < ns; c += 32) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] += Pcol[(c + u) * n + i];
+                for (int u = 0; u < 8; ++u) a[u] += Pcol[(c + 4 * u) * n + i];
             }
-            for (int u = 0; c < ns; ++c, ++u) a[u] += Pcol[c * n + i];
+            for (int u = 0; c < ns; c += 4, ++u) a[u] += Pcol[c * n + i];
         }
-        const T s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    gsum[g][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (g == 0 && i < n) {
+        const T s = (gsum[0][lane] + gsum[1][lane]) + (gsum[2][lane] + gsum[3][lane]);
         T o = var * s;
         if (pdiag) {
             o = tfma<T>(noise, pdiag[i], o);
@@ -343,7 +350,7 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
         CGLB_LAUNCH_CHECK(c);
     }
     if (c->kff_skip_combine) return CGLB_OK;
-    const int cgrid = (int)((n + 255) / 256);
+    const int cgrid = (int)((n + 63) / 64);  // 64 elements per block
     if (pdot_slot && cgrid > DOTPART_CAP) return cglb_fail(c, CGLB_ERR_BAD_ARG, "row shard too large for dot partials");
     hipLaunchKernelGGL((kff_sym_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)plain, (int)nplain, (const T*)Prow, nchunk,
                        (const T*)Pcol, n, chunk, RBROWS, world, rank, (T)c->var, (T)c->noise, cyclic ? (rank == 0 ? p_full : (const T*)nullptr) : p_full + c->r0, out_local,
