@@ -94,3 +94,57 @@ def test_logger_keys_and_stopwatch():
     assert not sw.started()
     sw.start(); sw.pause(); sw.resume()
     assert sw.stop() >= 0.0 and not sw.started()
+
+
+def test_inducing_init_dispatches_to_an_accelerated_selection_when_the_callback_offers_one():
+    """InducingVariableConfig.init(data, kernel_fn): a kernel callback that brings `select_inducing` (the hip backend's does:
+    cglb_select_inducing on the GPU) is used instead of the generic numpy loop; a plain callable goes through numpy."""
+    from cglb_amd.backend.config import InducingVariableConfig, greedy_conditional_variance
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((60, 2))
+    y = rng.standard_normal(60)
+
+    def plain(x1, x2=None, full_cov=False):
+        x1 = np.asarray(x1)
+        if not full_cov:
+            return np.ones(len(x1))
+        x2 = x1 if x2 is None else np.asarray(x2)
+        return np.exp(-0.5 * ((x1[:, None, :] - x2[None, :, :]) ** 2).sum(-1))
+
+    cfg = InducingVariableConfig(7)
+    Z_plain = cfg.init((X, y), plain)
+    np.testing.assert_array_equal(Z_plain, greedy_conditional_variance(X, 7, plain))
+
+    class Accelerated:
+        calls = []
+
+        def __call__(self, *a, **k):
+            raise AssertionError("the numpy path must not be used when select_inducing is offered")
+
+        def select_inducing(self, X, M):
+            self.calls.append((X.shape, M))
+            return X[:M] + 100.0
+
+    acc = Accelerated()
+    Z_acc = cfg.init((X, y), acc)
+    assert acc.calls == [((60, 2), 7)]
+    np.testing.assert_array_equal(Z_acc, X[:7] + 100.0)
+
+
+def test_init_kernel_callback_matches_the_oracle_kernels():
+    """The numpy closed form handed to a generic inducing-point initialiser (interface.py:278-284) against the oracle."""
+    from oracle import cglb_oracle as orc
+    from cglb_amd.backend.interface import _InitKernel
+    from cglb_amd.backend.models import BaseKernel, ScaleKernel
+    rng = np.random.default_rng(1)
+    X1, X2 = rng.standard_normal((9, 3)), rng.standard_normal((5, 3))
+    ls = np.array([0.7, 1.3, 2.0])
+    for kind in ("rbf", "matern32"):
+        base = BaseKernel(kind, ard_num_dims=3)
+        base.lengthscale = ls
+        k = ScaleKernel(base)
+        k.outputscale = 1.9
+        fn = _InitKernel(k)
+        np.testing.assert_allclose(fn(X1, X2, full_cov=True), orc.kernel_matrix(kind, X1, X2, ls, 1.9), rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(fn(X1), np.full(9, 1.9))
+        assert callable(fn.select_inducing)

@@ -186,3 +186,15 @@ def test_cli_train_and_metric_roundtrip(tmp_path):
                                    "-m", "cglb", "-i", "cv", "-M", "16", "-p", os.path.join(logdir, "model.json")], catch_exceptions=False)
     assert r2.exit_code == 0, r2.output
     assert os.path.exists(os.path.join(logdir, "metric.npy"))
+
+
+@pytest.mark.parametrize("kernel", ["Matern32", "rbf"])
+def test_create_model_initialises_inducing_points_on_the_gpu(kernel):
+    """create_model -> InducingVariableConfig.init -> cglb_select_inducing: the model's initial Z equals the numpy statement of
+    the greedy conditional-variance rule under the initial kernel (unit lengthscales, variance 1; config.py:74-76)."""
+    from cglb_amd.backend.config import greedy_conditional_variance
+    from cglb_amd.backend.interface import _InitKernel
+    be, model, (train, _) = _model(kernel, M=24)
+    Z = be.model_parameters(model)[".inducing_variable.Z"]
+    ref = greedy_conditional_variance(np.asarray(train[0]), 24, _InitKernel(model.covar_module.base_kernel).__call__)
+    np.testing.assert_array_equal(Z, ref)
