@@ -55,8 +55,9 @@ template <bool CLAMP> __device__ __forceinline__ double exp2_hot(double x) {
 }
 template <bool CLAMP> __device__ __forceinline__ float exp2_hot(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// sqrt for x >= 0: hardware rsq seed (relative error e0 <= ~2^-23 on fp64), one coupled Goldschmidt step (-> ~e0^2) and one
-// residual correction (-> ~e0^4, i.e. correctly rounded up to the last fma).  x == 0 returns 0.  8 instructions.
+// sqrt for x >= 0: hardware rsq seed (relative error e0 <= ~2^-23 on fp64), one Goldschmidt step on g (-> ~e0^2) and one
+// residual correction with the first-order h (-> ~e0^3, below the rounding of the last fma).  x == 0 returns 0.  7 instructions
+// + v_rsq_f64, which alone occupies 4 issue slots.
 __device__ __forceinline__ double sqrt_pos(double x) {
     const double xs = fmax(x, 1e-280);
     const double y = __builtin_amdgcn_rsq(xs);
@@ -64,7 +65,6 @@ __device__ __forceinline__ double sqrt_pos(double x) {
     double h = 0.5 * y;
     const double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
-    h = __builtin_fma(h, e, h);
     const double d = __builtin_fma(-g, g, xs);
     g = __builtin_fma(d, h, g);
     return x > 0.0 ? g : 0.0;
@@ -80,8 +80,7 @@ __device__ __forceinline__ double sqrt_hot(double x) {
     double h = 0.5 * y;
     const double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
-    h = __builtin_fma(h, e, h);
-    const double d = __builtin_fma(-g, g, xs);
+    const double d = __builtin_fma(-g, g, xs);  // residual ~ e0^2 xs: the first-order h (error e0) is accurate enough to apply it
     return __builtin_fma(d, h, g);
 }
 __device__ __forceinline__ float sqrt_hot(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
