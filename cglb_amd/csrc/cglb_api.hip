@@ -517,6 +517,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "kff_rows")) c->kff_rows = (int)value;
     else if (!strcmp(name, "sym_chunk")) c->sym_chunk_opt = value;
     else if (!strcmp(name, "pcg_lookahead")) c->pcg_lookahead = (int)value;
+    else if (!strcmp(name, "sym_order")) c->sym_order = (int)value;
     else if (!strcmp(name, "chol_mode")) c->chol_mode = (int)value;
     else if (!strcmp(name, "precond_mode")) { c->precond_mode = (int)value; c->have_local = c->have_terms = false; }
     else return cglb_fail(c, CGLB_ERR_BAD_ARG, std::string("unknown option ") + name);

@@ -57,6 +57,7 @@ struct cglb_ctx {
     size_t frag_cap = 0;
     void* sym_items = nullptr;       // work list (row block, column chunk) of the symmetric mat-vec
     int64_t sym_n = -1, sym_chunk = 0, sym_chunk_opt = 0;
+    int sym_order = 1, sym_order_built = -1;  // item order of the symmetric kernel: 0 row-block major, 1 XCD-aware (kernels_kff_sym.hip)
     int sym_rbrows = 0, sym_nitems = 0, sym_world = 1, sym_rank = 0;
     int par_world = 1, par_rank = 0;  // cyclic distribution of the symmetric K_ff work over ranks (cglb_set_parallel)
     void* slabs = nullptr;   // split-K partial A A^T slabs [nslab][M][M]

@@ -24,6 +24,7 @@
 // 2^(|x_j|^2/2); cglb_set_hypers keeps the whole exponent range inside +-1000 octaves (fp64) / +-100 (fp32) or selects CLAMP.
 #include "devmath.h"
 #include "dispatch.h"
+#include <algorithm>
 
 #define SYM_BATCH 16
 
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
     const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (item >= nitems) return;  // whole wave exits together
     const int2 it = items[item];
+    if (__builtin_amdgcn_readfirstlane(it.x) < 0) return;  // padding entry of the XCD-aware item order
     const int64_t rb = __builtin_amdgcn_readfirstlane(it.x), k = __builtin_amdgcn_readfirstlane(it.y);
     const int64_t cslot = rb / rb_stride;  // compact Pcol slot: with a cyclic rank distribution only every rb_stride-th block is here
     constexpr int RBROWS = 64 * R;
@@ -267,15 +269,49 @@ static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, i
                             int* nchunk_out) {
     const int nrb = (int)((n + rbrows - 1) / rbrows);
     const int nchunk = (int)((n + chunk - 1) / chunk);
-    if (c->sym_items && c->sym_n == n && c->sym_rbrows == rbrows && c->sym_chunk == chunk && c->sym_world == world && c->sym_rank == rank) {
+    if (c->sym_items && c->sym_n == n && c->sym_rbrows == rbrows && c->sym_chunk == chunk && c->sym_world == world && c->sym_rank == rank &&
+        c->sym_order_built == c->sym_order) {
         *nitems_out = c->sym_nitems; *nrb_out = nrb; *nchunk_out = nchunk;
         return CGLB_OK;
     }
     std::vector<int2> items;
-    // longest rows first (row block 0 sweeps the most columns): helps the tail of the launch
-    for (int rb = rank; rb < nrb; rb += world) {
-        const int k0 = (int)(((int64_t)rb * rbrows) / chunk);
-        for (int k = k0; k < nchunk; ++k) items.push_back(make_int2(rb, k));
+    if (c->sym_order == 0) {
+        // row-block major, longest rows first (row block 0 sweeps the most columns)
+        for (int rb = rank; rb < nrb; rb += world) {
+            const int k0 = (int)(((int64_t)rb * rbrows) / chunk);
+            for (int k = k0; k < nchunk; ++k) items.push_back(make_int2(rb, k));
+        }
+    } else {
+        // XCD-aware order.  Workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8), each with its own 4-MB L2, and the
+        // streamed side of an item is its column chunk (chunk * (DP + 2) operands, 80 KB at 1024 columns).  Items are sorted by
+        // column chunk and the sorted list is cut into 8 contiguous ranges of equal length, one per XCD: an XCD then only ever
+        // streams its own ~1/8 of the columns (L2-resident), instead of every XCD sweeping all of X through the Infinity Cache.
+        std::vector<int2> sorted;
+        for (int k = 0; k < nchunk; ++k) {
+            const int64_t last_row = (int64_t)(k + 1) * chunk - 1 < n - 1 ? (int64_t)(k + 1) * chunk - 1 : n - 1;
+            const int rb_hi = (int)(last_row / rbrows);  // row blocks whose first row is <= the last column of the chunk
+            for (int rb = rank; rb <= rb_hi && rb < nrb; rb += world)
+                if ((int)(((int64_t)rb * rbrows) / chunk) <= k) sorted.push_back(make_int2(rb, k));
+        }
+        const int XCDS = 8, WG = 4;
+        const size_t T = sorted.size();
+        size_t per_xcd = (T + XCDS - 1) / XCDS;
+        per_xcd = (per_xcd + WG - 1) / WG * WG;  // whole workgroups
+        const size_t groups = per_xcd / WG;      // workgroups per XCD
+        items.assign(per_xcd * XCDS, make_int2(-1, -1));
+        // inside an XCD's range (a dozen column chunks, ~1 MB of streamed operands that stay in its L2) go row block by row block,
+        // so that the 20 KB of row operands of a block are fetched once per XCD rather than once per item
+        for (size_t x = 0; x < (size_t)XCDS; ++x) {
+            const size_t lo = x * per_xcd < T ? x * per_xcd : T, hi = (x + 1) * per_xcd < T ? (x + 1) * per_xcd : T;
+            std::stable_sort(sorted.begin() + lo, sorted.begin() + hi, [](const int2& a, const int2& b) { return a.x < b.x; });
+        }
+        for (size_t x = 0; x < (size_t)XCDS; ++x)
+            for (size_t sgrp = 0; sgrp < groups; ++sgrp)
+                for (size_t w = 0; w < (size_t)WG; ++w) {
+                    const size_t src = x * per_xcd + sgrp * WG + w;
+                    const size_t b = sgrp * XCDS + x;  // workgroup index that lands on XCD x
+                    if (src < T) items[b * WG + w] = sorted[src];
+                }
     }
     if (c->sym_items) HIP_CHECK(c, hipFree(c->sym_items));
     c->sym_items = nullptr;
@@ -283,7 +319,7 @@ static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, i
     HIP_CHECK(c, hipMalloc(&c->sym_items, items.size() * sizeof(int2)));
     HIP_CHECK(c, hipMemcpyAsync(c->sym_items, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    c->sym_n = n; c->sym_rbrows = rbrows; c->sym_chunk = chunk; c->sym_world = world; c->sym_rank = rank;
+    c->sym_n = n; c->sym_rbrows = rbrows; c->sym_chunk = chunk; c->sym_world = world; c->sym_rank = rank; c->sym_order_built = c->sym_order;
     c->sym_nitems = (rank < nrb) ? (int)items.size() : 0;
     *nitems_out = c->sym_nitems; *nrb_out = nrb; *nchunk_out = nchunk;
     return CGLB_OK;

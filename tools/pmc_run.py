@@ -8,6 +8,8 @@ N, D, M = int(os.environ.get("N", 100000)), 8, 1024
 X, y, Z = synthetic_problem(N, D, M, 0)
 h = trained_like_hypers(D)
 ctx = HipContext(X, y, M, "rbf")
+if "SYM_ORDER" in os.environ:
+    ctx.set_option("sym_order", int(os.environ["SYM_ORDER"]))
 ctx.set_hypers(h["lengthscales"], h["variance"], h["noise"], h["mean"], Z, 1e-6)
 ctx.setup()
 ctx.time_kernel(0, 3)
