@@ -63,6 +63,7 @@ SIGNATURES = {
     "cglb_shard_obj_w": (c_int, [c_void_p, c_void_p]),
     "cglb_shard_obj_phase3_cyclic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cglb_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "cglb_get_stat": (c_int, [c_void_p, c_char_p, POINTER(c_double)]),
     "cglb_select_inducing": (c_int, [c_void_p, POINTER(c_double), c_double, c_double, POINTER(c_int64), c_void_p, POINTER(c_double)]),
     "cglb_get_matrix": (c_int, [c_void_p, c_int, c_void_p]),
     "cglb_time_kernel": (c_int, [c_void_p, c_int, c_int, POINTER(c_double)]),

@@ -503,6 +503,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
                     c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t ev : c->k1_events) (void)hipEventDestroy(ev);
     if (c->host_scal) (void)hipHostFree(c->host_scal);
     if (c->scal_event) (void)hipEventDestroy(c->scal_event);
     if (c->blas) (void)rocblas_destroy_handle(c->blas);
@@ -518,6 +519,11 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "sym_chunk")) c->sym_chunk_opt = value;
     else if (!strcmp(name, "pcg_lookahead")) c->pcg_lookahead = (int)value;
     else if (!strcmp(name, "sym_order")) c->sym_order = (int)value;
+    else if (!strcmp(name, "k1_profile")) {  // 1: start timing every launch of the symmetric pair kernel (counters reset), 0: stop
+        if (value) { c->k1_events_used = 0; c->k1_ms_total = 0.0; c->k1_launches = 0; }
+        else CGLB_TRY(k1_profile_collect(c));
+        c->k1_profile = value != 0;
+    }
     else if (!strcmp(name, "chol_mode")) c->chol_mode = (int)value;
     else if (!strcmp(name, "precond_mode")) { c->precond_mode = (int)value; c->have_local = c->have_terms = false; }
     else return cglb_fail(c, CGLB_ERR_BAD_ARG, std::string("unknown option ") + name);
@@ -918,6 +924,16 @@ int cglb_get_matrix(cglb_ctx* c, int which, void* dst) {
     }
     HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return CGLB_OK;
+}
+
+int cglb_get_stat(cglb_ctx* c, const char* name, double* value) {
+    if (!c || !name || !value) return CGLB_ERR_BAD_ARG;
+    if (!strcmp(name, "k1_ms_total") || !strcmp(name, "k1_launches")) {
+        CGLB_TRY(k1_profile_collect(c));
+        *value = !strcmp(name, "k1_ms_total") ? c->k1_ms_total : (double)c->k1_launches;
+        return CGLB_OK;
+    }
+    return cglb_fail(c, CGLB_ERR_BAD_ARG, std::string("unknown statistic ") + name);
 }
 
 int cglb_time_kernel(cglb_ctx* c, int which, int reps, double* ms_avg) {

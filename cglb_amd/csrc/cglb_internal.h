@@ -57,6 +57,13 @@ struct cglb_ctx {
     size_t frag_cap = 0;
     void* sym_items = nullptr;       // work list (row block, column chunk) of the symmetric mat-vec
     int64_t sym_n = -1, sym_chunk = 0, sym_chunk_opt = 0;
+    // in-situ timing of the dominant kernel (cglb_set_option "k1_profile", cglb_get_stat): HIP event pairs around every launch of the
+    // symmetric pair kernel on the context stream, resolved lazily
+    bool k1_profile = false;
+    std::vector<hipEvent_t> k1_events;
+    size_t k1_events_used = 0;
+    double k1_ms_total = 0.0;
+    long long k1_launches = 0;
     int sym_order = 1, sym_order_built = -1;  // item order of the symmetric kernel: 0 row-block major, 1 XCD-aware (kernels_kff_sym.hip)
     int sym_rbrows = 0, sym_nitems = 0, sym_world = 1, sym_rank = 0;
     int par_world = 1, par_rank = 0;  // cyclic distribution of the symmetric K_ff work over ranks (cglb_set_parallel)
@@ -136,7 +143,8 @@ int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* 
 int launch_cholesky_lower(cglb_ctx* c, void* A, int* info_slot);
 int launch_frag_prep(cglb_ctx* c);
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
-int launch_hot_weights(cglb_ctx* c);  // wh = 2^(xah/T) after set_hypers (RBF)
+int launch_hot_weights(cglb_ctx* c);
+int k1_profile_collect(cglb_ctx* c);  // resolves the pending event pairs into k1_ms_total / k1_launches  // wh = 2^(xah/T) after set_hypers (RBF)
 int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial);  // this rank's share of the global upper triangle
 int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, double* out_dl);
 int launch_kff_plain_range(cglb_ctx* c, const void* p_full, int64_t col0, int64_t col1, void* part, int64_t* nslots);

@@ -369,21 +369,37 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     T* Pcol = Prow + (int64_t)nchunk * n;
     const int grid = (nitems + 3) / 4;
     if (grid > 0) {
-        if (c->exp_clamp) {
+        if (!c->exp_clamp && KIND == CGLB_RBF) {  // folded column norm: pre-weight the operand over the columns of this block
+            hipLaunchKernelGGL((weight_operand_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, p_full + row0,
+                               (const T*)c->wh + row0, n, (T*)c->pwh + row0);
+            CGLB_LAUNCH_CHECK(c);
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->k1_profile) {  // in-situ timing of the dominant kernel (cglb_get_stat)
+            if (c->k1_events_used + 2 > c->k1_events.size()) {
+                if (c->k1_events.size() >= 4096) CGLB_TRY(k1_profile_collect(c));  // bounded pool: resolve (synchronises) and reuse
+                else
+                    for (int q = 0; q < 2; ++q) {
+                        hipEvent_t ev;
+                        HIP_CHECK(c, hipEventCreate(&ev));
+                        c->k1_events.push_back(ev);
+                    }
+            }
+            e0 = c->k1_events[c->k1_events_used];
+            e1 = c->k1_events[c->k1_events_used + 1];
+            c->k1_events_used += 2;
+            HIP_CHECK(c, hipEventRecord(e0, c->stream));
+        }
+        if (c->exp_clamp)
             hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full,
                                (const T*)nullptr, (const T*)nullptr, row0, n, chunk, (const int2*)c->sym_items, nitems, world, Prow, Pcol,
                                (const double*)c->exp_tab);
-        } else {
-            if (KIND == CGLB_RBF) {  // folded column norm: pre-weight the operand over the columns of this block
-                hipLaunchKernelGGL((weight_operand_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, p_full + row0,
-                                   (const T*)c->wh + row0, n, (T*)c->pwh + row0);
-                CGLB_LAUNCH_CHECK(c);
-            }
+        else
             hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full,
                                (const T*)c->pwh, (const T*)c->wh, row0, n, chunk, (const int2*)c->sym_items, nitems, world, Prow, Pcol,
                                (const double*)c->exp_tab);
-        }
         CGLB_LAUNCH_CHECK(c);
+        if (e1) HIP_CHECK(c, hipEventRecord(e1, c->stream));
     }
     if (c->kff_skip_combine) return CGLB_OK;
     const int cgrid = (int)((n + 63) / 64);  // 64 elements per block
@@ -396,6 +412,18 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
         hipLaunchKernelGGL(finalize_sum_sym_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, cgrid, pdot_slot);
         CGLB_LAUNCH_CHECK(c);
     }
+    return CGLB_OK;
+}
+
+int k1_profile_collect(cglb_ctx* c) {
+    for (size_t q = 0; q + 1 < c->k1_events_used; q += 2) {
+        HIP_CHECK(c, hipEventSynchronize(c->k1_events[q + 1]));
+        float ms = 0.f;
+        HIP_CHECK(c, hipEventElapsedTime(&ms, c->k1_events[q], c->k1_events[q + 1]));
+        c->k1_ms_total += ms;
+        c->k1_launches += 1;
+    }
+    c->k1_events_used = 0;
     return CGLB_OK;
 }
 

@@ -197,6 +197,11 @@ class HipContext:
         _lib.check(self.lib.cglb_predict(self._ctx, _ptr(v), _ptr(xn), xn.shape[0], _ptr(mean), _ptr(var)), self._ctx)
         return mean, var
 
+    def get_stat(self, name: str) -> float:
+        out = c_double()
+        _lib.check(self.lib.cglb_get_stat(self._ctx, name.encode(), byref(out)), self._ctx)
+        return out.value
+
     def time_kernel(self, which: int, reps: int) -> float:
         ms = c_double()
         _lib.check(self.lib.cglb_time_kernel(self._ctx, int(which), int(reps), byref(ms)), self._ctx)

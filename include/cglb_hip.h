@@ -174,7 +174,11 @@ int cglb_get_matrix(cglb_ctx* ctx, int which, void* dst);
  * which = 0: K_ff mat-vec (pair kernel + slab combine), 1: preconditioner apply, 2: gradient bilinear pass,
  * 3: the pair kernel of the mat-vec alone (the dominant kernel), 4: the same for this rank's cyclic share (cglb_set_parallel). */
 int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
-/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" ...;
+/* In-situ measurement of the dominant kernel: after cglb_set_option(ctx, "k1_profile", 1) every launch of the symmetric pair
+ * kernel (in mat-vecs, solves and evaluations alike) is bracketed by HIP events on the context stream; "k1_ms_total" and
+ * "k1_launches" return the accumulated device time and launch count since then (the call synchronises with the pending launches). */
+int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
+/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" | "sym_order" | "k1_profile" ...;
  * returns CGLB_ERR_BAD_ARG if unknown. */
 int cglb_set_option(cglb_ctx* ctx, const char* name, int64_t value);
 
