@@ -113,3 +113,26 @@ def test_lookahead_stop_test_does_not_change_results(name, max_error):
         outs.append((v.cpu().numpy(), steps, half))
     assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
     assert np.array_equal(outs[0][0], outs[1][0])
+
+
+def test_in_situ_kernel_timing_counts_every_matvec_of_a_solve():
+    """k1_profile brackets each launch of the symmetric pair kernel with HIP events: a cold-start solve of `steps` iterations
+    launches it steps + (number of restarts) times (the initial mat-vec is skipped for v0 = 0, no look-ahead here)."""
+    from conftest import load_golden
+    from cglb_amd.hip_context import HipContext
+    g = load_golden("rbf_d8_restart")
+    ctx = HipContext(g["X"], g["y"], g["Z"].shape[0], int(g["kind"]))
+    ctx.set_option("pcg_lookahead", 0)
+    ctx.set_hypers(g["lengthscales"], float(g["variance"]), float(g["noise"]), float(g["mean"]), g["Z"], float(g["jitter"]))
+    ctx.setup()
+    b = torch.from_numpy(g["y"] - float(g["mean"]))
+    ctx.set_option("k1_profile", 1)
+    v, steps, half = ctx.pcg(b, torch.zeros(len(b), dtype=torch.float64), float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+    launches, ms = ctx.get_stat("k1_launches"), ctx.get_stat("k1_ms_total")
+    ctx.set_option("k1_profile", 0)
+    restarts = sum(1 for i in range(steps) if i % int(g["restart_cg_iter"]) == int(g["restart_cg_iter"]) - 1)
+    assert launches == steps + restarts and ms > 0
+    with pytest.raises(ValueError):
+        ctx.get_stat("no_such_statistic")
+    ctx.matvec(torch.from_numpy(g["y"]))  # not profiled any more
+    assert ctx.get_stat("k1_launches") == launches
