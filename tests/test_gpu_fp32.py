@@ -10,10 +10,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kind", ["rbf", "matern32"])
-@pytest.mark.parametrize("variant", [0, 2])
-def test_fp32_matvec_and_objective(kind, variant):
+@pytest.mark.parametrize("variant,D", [(0, 8), (2, 8), (2, 16), (2, 12), (2, 24), (2, 3)])
+def test_fp32_matvec_and_objective(kind, variant, D):
+    """D = 16 is config C5's input dimension; 12/16 run 4 rows per lane in fp32 (2 in fp64), 24 runs 2."""
     from cglb_amd.hip_context import HipContext
-    N, D, M = 1500, 8, 32
+    N, M = 1500, 32
     X, y, Z = orc.synthetic_problem(N, D, M, seed=21)
     hyp = orc.trained_like_hypers(D, Z)
     hyp.noise = 0.5

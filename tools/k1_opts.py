@@ -7,7 +7,8 @@ from cglb_amd.hip_context import HipContext
 N = int(os.environ.get("N", 100000)); D = int(os.environ.get("D", 8)); kind = os.environ.get("KIND", "rbf")
 X, y, Z = synthetic_problem(N, D, 64, 0)
 h = trained_like_hypers(D)
-ctx = HipContext(X, y, 64, kind)
+dtype = torch.float32 if os.environ.get("DTYPE", "fp64") == "fp32" else torch.float64
+ctx = HipContext(X, y, 64, kind, dtype=dtype)
 ctx.set_hypers(h["lengthscales"], h["variance"], h["noise"], h["mean"], Z, 1e-6)
 for spec in sys.argv[1:]:
     for kv in spec.split(","):

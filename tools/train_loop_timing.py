@@ -1,0 +1,27 @@
+"""Developer tool: end-to-end cost of the training loop through the cglb.backend mirror at the headline shape:
+create_model (GPU inducing-point selection) + optimize (SciPy L-BFGS-B over the HIP objective) for a few steps, against the
+bare evaluation rate of bench.py."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from cglb_amd.backend import BACKENDS, CGLBConfig, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS
+from cglb_amd.backend.callbacks import Logger
+from cglb_amd.data import synthetic_problem
+
+N, D, M = int(os.environ.get("N", 100000)), int(os.environ.get("D", 8)), int(os.environ.get("M", 1024))
+steps = int(os.environ.get("STEPS", 6))
+X, y, _ = synthetic_problem(N, D, 8, 0)
+be = BACKENDS["hip"]
+be.configure_backend(logdir="/tmp/cglb_train_timing", keops=False)
+be.set_default_float("fp64"); be.set_default_jitter("fp64")
+t0 = time.perf_counter()
+model = be.create_model(CGLBConfig(kernel=KERNEL_CONFIGS["rbf"](), inducing_variable=INDUCING_VARIABLE_CONFIGS["cv"](M)), (X, y))
+torch.cuda.synchronize(); t_create = time.perf_counter() - t0
+data = ((X, y), (X[:1000], y[:1000]))
+logger = Logger("/tmp/cglb_train_timing", be.metrics_fn(model, data), lambda: be.model_parameters(model), holdout_interval=10**9, verbose=False)
+t0 = time.perf_counter()
+results = be.optimize(model, data, steps, logger, "scipy")
+torch.cuda.synchronize(); t_opt = time.perf_counter() - t0
+nfev = sum(r.nfev for r in results); nit = sum(r.nit for r in results)
+print(f"N={N} D={D} M={M}: create_model {t_create:.2f} s (incl. GPU inducing-point selection); optimize {nit} iterations / {nfev} evaluations "
+      f"in {t_opt:.2f} s = {1e3*t_opt/max(nfev,1):.1f} ms per evaluation; final loss {results[-1].fun:.4f}", flush=True)
