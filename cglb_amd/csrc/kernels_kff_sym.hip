@@ -331,7 +331,7 @@ static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, i
 template <typename T, int KIND, int DP>
 static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* pdot_slot, bool cyclic) {
     // rows per lane: bounded by the VGPR budget (R * DP operands of sizeof(T)); fp32 operands are half the size
-    constexpr int R = sizeof(T) == 8 ? ((DP <= 8) ? 4 : (DP <= 16 ? 2 : 1)) : ((DP <= 16) ? 4 : 2);
+    constexpr int R = sizeof(T) == 8 ? ((DP <= 4) ? 8 : (DP <= 8) ? 4 : (DP <= 16 ? 2 : 1)) : ((DP <= 4) ? 8 : (DP <= 16) ? 4 : 2);
     constexpr int RBROWS = 64 * R;
     const int64_t n = cyclic ? c->N : c->nloc;
     const int64_t row0 = cyclic ? 0 : c->r0;
