@@ -14,7 +14,8 @@
 //   * nothing is accumulated with atomics: every (slot, element) of the partial slabs is written by exactly one
 //     wave and the combine kernel adds the valid slots in fixed order, so results are bitwise reproducible.
 // Slab layout (element type double), n = number of rows of the square block:
-//   Prow[k][i], k < nchunk : row sums of chunk k (valid for k >= first chunk of row block rb(i))
+//   Prow[k][li], k < nchunk : row sums of chunk k (valid for k >= first chunk of row block rb(i)); li = compact index of row i among
+//                            the row blocks of this rank (all rows on one GPU), leading dimension prow_ld
 //   Pcol[rb][j], rb < nrb  : column sums produced by row block rb (valid for rb < rb(j))
 // The diagonal 64R x 64R blocks are evaluated in full and contribute row sums only.
 //
@@ -32,7 +33,7 @@ template <typename T, int KIND, int DP, int R, bool CLAMP>
 __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
                                                       const T* __restrict__ pw, const T* __restrict__ wcol,
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items, int nitems,
-                                                      int rb_stride, T* __restrict__ Prow, T* __restrict__ Pcol,
+                                                      int rb_stride, int64_t prow_ld, T* __restrict__ Prow, T* __restrict__ Pcol,
                                                       const double* __restrict__ exp_tab) {
     __shared__ double tab[CGLB_TAB_SIZE];
     load_exp_table(tab, exp_tab);  // before the early exit below: every thread reaches the barrier inside
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t row = rbase + r * 64 + lane;
-        if (row < n) Prow[k * n + row] = acc[r];
+        if (row < n) Prow[k * prow_ld + cslot * RBROWS + r * 64 + lane] = acc[r];  // compact: only this rank's row blocks have rows here
     }
 }
 
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
 // (One thread per element left a rank of a cyclic run with ~400 dependent slab reads on 1/world of its threads: 46 us at world 8.)
 template <typename T>
 __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restrict__ plain, int nplain, const T* __restrict__ Prow, int nchunk,
-                                                              const T* __restrict__ Pcol, int64_t n, int64_t chunk, int rbrows, int world, int rank,
+                                                              int64_t prow_ld, const T* __restrict__ Pcol, int64_t n, int64_t chunk, int rbrows, int world,
+                                                              int rank,
                                                               T var, T noise, const T* __restrict__ pdiag, T* __restrict__ out,
                                                               double* __restrict__ dotpart) {
     __shared__ double smem[16];
@@ -203,12 +205,13 @@ __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restric
         const int64_t rbi = i / rbrows;
         if (rbi % world == rank) {
             const int64_t k0 = (rbi * rbrows) / chunk;
+            const int64_t li = (rbi / world) * rbrows + (i - rbi * rbrows);  // compact row index among this rank's row blocks
             int64_t k = k0 + g;
             for (; k + 28 < nchunk; k += 32) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] += Prow[(k + 4 * u) * n + i];
+                for (int u = 0; u < 8; ++u) a[u] += Prow[(k + 4 * u) * prow_ld + li];
             }
-            for (int u = 0; k < nchunk; k += 4, ++u) a[u] += Prow[k * n + i];
+            for (int u = 0; k < nchunk; k += 4, ++u) a[u] += Prow[k * prow_ld + li];
         }
         {
             const int64_t ns = rbi > rank ? (rbi - rank + world - 1) / world : 0;  // column-sum slots 0 .. ns-1 are valid for this element
@@ -336,9 +339,14 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     const int64_t n = cyclic ? c->N : c->nloc;
     const int64_t row0 = cyclic ? 0 : c->r0;
     const int world = cyclic ? c->par_world : 1, rank = cyclic ? c->par_rank : 0;
-    // column chunk per work item: 1024 on one GPU; with the work dealt to `world` ranks the items of a rank must still fill the
-    // chip (measured per-rank kernel at N=100k: world 8: 0.48 ms at 128, 0.63 ms at 1024; ideal 0.45)
-    int64_t chunk = c->sym_chunk_opt > 0 ? c->sym_chunk_opt : (1024 / world < 128 ? 128 : 1024 / world);
+    // (measured per-rank kernel at N=100k: world 8: 0.48 ms at 128, 0.63 ms at 1024; world 4: 0.82 at 256, 0.86 at 512) -> halve the
+    // 1024-column chunk until a rank has >= 16k items; large N keeps 1024 at any world size (fewer, larger slabs)
+    int64_t chunk = 1024;
+    {
+        const double nrb_rank = (double)((n + RBROWS - 1) / RBROWS) / world;
+        while (chunk > 128 && nrb_rank * ((double)n / (double)chunk) * 0.5 < 16384.0) chunk /= 2;
+    }
+    if (c->sym_chunk_opt > 0) chunk = c->sym_chunk_opt;
     chunk = (chunk + SYM_BATCH - 1) / SYM_BATCH * SYM_BATCH;
     int nitems = 0, nrb = 0, nchunk = 0;
     CGLB_TRY(ensure_sym_items(c, n, RBROWS, chunk, world, rank, &nitems, &nrb, &nchunk));
@@ -347,7 +355,8 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     const int64_t nleft = cyclic ? 0 : c->r0, nright = cyclic ? 0 : c->N - c->r1;
     int64_t plain_slots_max = 0;
     if (nleft > 0 || nright > 0) plain_slots_max = 2 * 512;
-    const size_t need = ((size_t)plain_slots_max + nchunk + ncslot) * n * sizeof(T);
+    const int64_t prow_ld = (int64_t)ncslot * RBROWS;  // compact rows of this rank's row blocks
+    const size_t need = (((size_t)plain_slots_max + ncslot) * n + (size_t)nchunk * prow_ld) * sizeof(T);
     if (need > c->kpart_cap) {
         if (c->kpart) HIP_CHECK(c, hipFree(c->kpart));
         c->kpart = nullptr;
@@ -367,7 +376,7 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
         nplain += ns;
     }
     T* Prow = plain + nplain * n;
-    T* Pcol = Prow + (int64_t)nchunk * n;
+    T* Pcol = Prow + (int64_t)nchunk * prow_ld;
     const int grid = (nitems + 3) / 4;
     if (grid > 0) {
         if (!c->exp_clamp && KIND == CGLB_RBF) {  // folded column norm: pre-weight the operand over the columns of this block
@@ -393,11 +402,11 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
         }
         if (c->exp_clamp)
             hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full,
-                               (const T*)nullptr, (const T*)nullptr, row0, n, chunk, (const int2*)c->sym_items, nitems, world, Prow, Pcol,
+                               (const T*)nullptr, (const T*)nullptr, row0, n, chunk, (const int2*)c->sym_items, nitems, world, prow_ld, Prow, Pcol,
                                (const double*)c->exp_tab);
         else
             hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full,
-                               (const T*)c->pwh, (const T*)c->wh, row0, n, chunk, (const int2*)c->sym_items, nitems, world, Prow, Pcol,
+                               (const T*)c->pwh, (const T*)c->wh, row0, n, chunk, (const int2*)c->sym_items, nitems, world, prow_ld, Prow, Pcol,
                                (const double*)c->exp_tab);
         CGLB_LAUNCH_CHECK(c);
         if (e1) HIP_CHECK(c, hipEventRecord(e1, c->stream));
@@ -406,7 +415,7 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     const int cgrid = (int)((n + 63) / 64);  // 64 elements per block
     if (pdot_slot && cgrid > DOTPART_CAP) return cglb_fail(c, CGLB_ERR_BAD_ARG, "row shard too large for dot partials");
     hipLaunchKernelGGL((kff_sym_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)plain, (int)nplain, (const T*)Prow, nchunk,
-                       (const T*)Pcol, n, chunk, RBROWS, world, rank, (T)c->var, (T)c->noise, cyclic ? (rank == 0 ? p_full : (const T*)nullptr) : p_full + c->r0, out_local,
+                       prow_ld, (const T*)Pcol, n, chunk, RBROWS, world, rank, (T)c->var, (T)c->noise, cyclic ? (rank == 0 ? p_full : (const T*)nullptr) : p_full + c->r0, out_local,
                        pdot_slot ? c->dotpart : nullptr);
     CGLB_LAUNCH_CHECK(c);
     if (pdot_slot) {

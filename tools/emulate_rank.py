@@ -34,6 +34,8 @@ h = trained_like_hypers(D)
 per, parts = row_partition(N, world)
 rank = 0
 ctx = HipContext(X, y, M, "rbf", row_range=parts[rank])
+if "SYM_CHUNK" in os.environ:
+    ctx.set_option("sym_chunk", int(os.environ["SYM_CHUNK"]))
 ctx.set_hypers(h["lengthscales"], h["variance"], h["noise"], h["mean"], Z, 1e-6)
 drv = SymShardedCGLB(HipSymLocalOps(ctx), FakeComm(world, rank))
 t0 = time.perf_counter(); drv.setup(); torch.cuda.synchronize(); t_setup = time.perf_counter() - t0
