@@ -131,39 +131,66 @@ int launch_sub_scalar(cglb_ctx* c, void* out, const void* y_local, double mean, 
     return CGLB_OK;
 }
 
-// ---- u = A_loc r : one row of the [M][nloc] panel per block group (HBM-bound, 16-B loads) ------------------
-// grid = (M, nsplit): block (m, s) reduces columns [s*chunk, (s+1)*chunk) of row m; partials [M][nsplit].
+// ---- u = A_loc r : GU_ROWS rows of the [M][nloc] panel per block (HBM-bound, 16-B loads) ------------------------------
+// grid = (ceil(M / GU_ROWS), nsplit): block (b, s) reduces columns [s*chunk, (s+1)*chunk) of rows GU_ROWS*b ...; partials [M][nsplit].
+// One load of r serves GU_ROWS panel rows (with one row per block r was re-read from L2 once per panel row: as many L2 bytes as
+// HBM bytes) and GU_ROWS independent 16-B panel loads are in flight per thread.
+#define GU_ROWS 4
 template <typename T>
-__global__ __launch_bounds__(256) void gemv_u_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ r, int64_t nloc,
+__global__ __launch_bounds__(256) void gemv_u_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ r, int64_t nloc, int M,
                                                      int64_t chunk, double* __restrict__ upart) {
-    __shared__ double smem[16];
-    const int m = blockIdx.x;
+    __shared__ double smem[GU_ROWS][4];
+    const int m0 = blockIdx.x * GU_ROWS;
     const int64_t n0 = (int64_t)blockIdx.y * chunk;
     const int64_t n1 = (n0 + chunk < nloc) ? n0 + chunk : nloc;
-    const T* __restrict__ row = A + (int64_t)m * lda;
+    const T* __restrict__ row[GU_ROWS];
+#pragma unroll
+    for (int q = 0; q < GU_ROWS; ++q) row[q] = A + (int64_t)(m0 + q < M ? m0 + q : M - 1) * lda;  // clamped rows are computed and dropped
     constexpr int V = 16 / sizeof(T);
-    double s = 0.0;
-    // vector body when the row start is 16-B aligned
+    double s[GU_ROWS];
+#pragma unroll
+    for (int q = 0; q < GU_ROWS; ++q) s[q] = 0.0;
     int64_t i = n0 + (int64_t)threadIdx.x * V;
-    const bool aligned = ((((uintptr_t)(row + n0)) | ((uintptr_t)(r + n0))) & 15) == 0;
+    // vector body when the row starts are 16-B aligned (lda is a multiple of 8 elements)
+    const bool aligned = ((((uintptr_t)(row[0] + n0)) | ((uintptr_t)(r + n0)) | (uintptr_t)(lda * sizeof(T))) & 15) == 0;
     if (aligned) {
         using VT = typename std::conditional<sizeof(T) == 8, double2, float4>::type;
         for (; i + V <= n1; i += (int64_t)blockDim.x * V) {
-            const VT a = *reinterpret_cast<const VT*>(row + i);
             const VT b = *reinterpret_cast<const VT*>(r + i);
-            if constexpr (sizeof(T) == 8) {
-                s += (double)a.x * (double)b.x + (double)a.y * (double)b.y;
-            } else {
-                s += (double)a.x * (double)b.x + (double)a.y * (double)b.y + (double)a.z * (double)b.z + (double)a.w * (double)b.w;
+            VT a[GU_ROWS];
+#pragma unroll
+            for (int q = 0; q < GU_ROWS; ++q) a[q] = *reinterpret_cast<const VT*>(row[q] + i);
+#pragma unroll
+            for (int q = 0; q < GU_ROWS; ++q) {
+                if constexpr (sizeof(T) == 8) {
+                    s[q] += (double)a[q].x * (double)b.x + (double)a[q].y * (double)b.y;
+                } else {
+                    s[q] += (double)a[q].x * (double)b.x + (double)a[q].y * (double)b.y + (double)a[q].z * (double)b.z + (double)a[q].w * (double)b.w;
+                }
             }
         }
         // tail (at most V-1 elements, handled by the thread whose i landed there)
-        for (int64_t k = i; k < n1 && k < i + V; ++k) s += (double)row[k] * (double)r[k];
+        for (int64_t k = i; k < n1 && k < i + V; ++k) {
+#pragma unroll
+            for (int q = 0; q < GU_ROWS; ++q) s[q] += (double)row[q][k] * (double)r[k];
+        }
     } else {
-        for (int64_t k = n0 + threadIdx.x; k < n1; k += blockDim.x) s += (double)row[k] * (double)r[k];
+        for (int64_t k = n0 + threadIdx.x; k < n1; k += blockDim.x) {
+#pragma unroll
+            for (int q = 0; q < GU_ROWS; ++q) s[q] += (double)row[q][k] * (double)r[k];
+        }
     }
-    s = block_sum(s, smem);
-    if (threadIdx.x == 0) upart[(int64_t)m * gridDim.y + blockIdx.y] = s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < GU_ROWS; ++q) {
+        const double w = wave_sum(s[q]);
+        if (lane == 0) smem[q][wid] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < GU_ROWS && m0 + (int)threadIdx.x < M) {
+        const int q = threadIdx.x;
+        upart[(int64_t)(m0 + q) * gridDim.y + blockIdx.y] = (smem[q][0] + smem[q][1]) + (smem[q][2] + smem[q][3]);
+    }
 }
 
 template <typename T>
@@ -178,7 +205,7 @@ __global__ __launch_bounds__(256) void gemv_u_finalize_kernel(const double* __re
 int launch_gemv_u(cglb_ctx* c, const void* r_local, void* u_out) {
     int nsplit = 1;
     // enough blocks to fill the chip: M * nsplit >= ~2048
-    while ((int64_t)c->M * nsplit < 2048 && nsplit < 64 && c->nloc / (nsplit * 2) >= 4096) nsplit *= 2;
+    while ((int64_t)c->M / GU_ROWS * nsplit < 2048 && nsplit < 64 && c->nloc / (nsplit * 2) >= 4096) nsplit *= 2;
     int64_t chunk = (c->nloc + nsplit - 1) / nsplit;
     chunk = (chunk + 7) & ~(int64_t)7;  // keeps 16-B alignment of chunk starts when nloc*esz is 16-B aligned
     if (chunk == 0) chunk = 8;
@@ -191,9 +218,9 @@ int launch_gemv_u(cglb_ctx* c, const void* r_local, void* u_out) {
         HIP_CHECK(c, hipMalloc((void**)&c->gpart, need));
         c->gpart_cap = need;
     }
-    dim3 grid((unsigned)c->M, (unsigned)nsplit);
+    dim3 grid((unsigned)((c->M + GU_ROWS - 1) / GU_ROWS), (unsigned)nsplit);
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((gemv_u_kernel<T>), grid, dim3(256), 0, c->stream, (const T*)c->At, c->lda,
-                                                 (const T*)r_local, c->nloc, chunk, c->gpart));
+                                                 (const T*)r_local, c->nloc, c->M, chunk, c->gpart));
     CGLB_LAUNCH_CHECK(c);
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((gemv_u_finalize_kernel<T>), dim3((c->M + 255) / 256), dim3(256), 0, c->stream,
                                                  (const double*)c->gpart, c->M, nsplit, (T*)u_out));
