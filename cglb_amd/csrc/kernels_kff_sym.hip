@@ -28,9 +28,10 @@
 #include <algorithm>
 
 #define SYM_BATCH 16
+typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane side by side: v_pk_fma_f32 (fp32 path)
 
 template <typename T, int KIND, int DP, int R, bool CLAMP>
-__global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
                                                       const T* __restrict__ pw, const T* __restrict__ wcol,
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items, int nitems,
                                                       int rb_stride, int64_t prow_ld, T* __restrict__ Prow, T* __restrict__ Pcol,
@@ -50,17 +51,35 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
     const int64_t cslot = rb / rb_stride;  // compact Pcol slot: with a cyclic rank distribution only every rb_stride-th block is here
     constexpr int RBROWS = 64 * R;
     const int64_t rbase = rb * RBROWS;
-    T xi[R][DP], ai[R], pr[R], acc[R];
+    // fp32: rows in pairs, so that the Gram chain and the two accumulations run as v_pk_fma_f32 (4.8 nominal cycles per pair of
+    // fma against 2 x 2.94 unpacked); the column operand is broadcast to both halves through op_sel straight from the SGPR
+    constexpr bool PACKED = (sizeof(T) == 4) && (R % 2 == 0);
+    constexpr int RP = PACKED ? R / 2 : 1;
+    constexpr int RU = PACKED ? 1 : R;  // the unpacked row operands exist only on the other path
+    T xi[RU][DP], ai[R], pr[R], acc[R];
+    sym_f2 xi2[RP][DP], ai2[RP], pr2[RP], acc2[RP];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t row = rbase + r * 64 + lane;
         const int64_t rr = row < n ? row : n - 1;
 #pragma unroll
-        for (int d = 0; d < DP; ++d) xi[r][d] = Xs[(row0 + rr) * DP + d];
+        for (int d = 0; d < DP; ++d) {
+            const T v = Xs[(row0 + rr) * DP + d];
+            if (PACKED) xi2[r / 2][d][r % 2] = (float)v;
+            else xi[r % RU][d] = v;
+        }
         const T a = xa[row0 + rr];
         ai[r] = (KIND == CGLB_RBF) ? a : T(-0.5) * a;
         pr[r] = row < n ? p[row0 + rr] : T(0);
         acc[r] = 0;
+    }
+    if (PACKED) {
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp) {
+            ai2[rp] = sym_f2{(float)ai[2 * rp], (float)ai[2 * rp + 1]};
+            pr2[rp] = sym_f2{(float)pr[2 * rp], (float)pr[2 * rp + 1]};
+            acc2[rp] = sym_f2{0.f, 0.f};
+        }
     }
     int64_t j0 = k * chunk;
     if (j0 < rbase) j0 = rbase;
@@ -98,12 +117,23 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
             }
             __builtin_amdgcn_sched_barrier(0);  // issue the prefetch first; it is consumed a whole column later
             T gram[R];
+            if (PACKED) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                T g = ai[r];
+                for (int rp = 0; rp < RP; ++rp) {
+                    sym_f2 g = ai2[rp];
 #pragma unroll
-                for (int d = 0; d < DP; ++d) g = tfma<T>(xi[r][d], xj[d], g);
-                gram[r] = g;
+                    for (int d = 0; d < DP; ++d) g = __builtin_elementwise_fma(xi2[rp][d], sym_f2{(float)xj[d], (float)xj[d]}, g);
+                    gram[2 * rp] = (T)g.x;
+                    gram[2 * rp + 1] = (T)g.y;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    T g = ai[r];
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) g = tfma<T>(xi[r % RU][d], xj[d], g);
+                    gram[r] = g;
+                }
             }
             KappaPend<T> kp[R];
 #pragma unroll
@@ -113,18 +143,34 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
             for (int r = 0; r < R; ++r) kappa_hot_poly<T, KIND>(kp[r]);
             __builtin_amdgcn_sched_barrier(0);  // ... and are first needed here, R polynomials later
             T tj = 0;
+            if (PACKED) {
+                sym_f2 tj2 = {0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const T kap = kappa_hot_end<T, KIND>(kp[r]);
-                acc[r] = tfma<T>(kap, pj, acc[r]);
-                tj = tfma<T>(kap, pr[r], tj);
+                for (int rp = 0; rp < RP; ++rp) {
+                    const sym_f2 kap2 = {(float)kappa_hot_end<T, KIND>(kp[2 * rp]), (float)kappa_hot_end<T, KIND>(kp[2 * rp + 1])};
+                    acc2[rp] = __builtin_elementwise_fma(kap2, sym_f2{(float)pj, (float)pj}, acc2[rp]);
+                    tj2 = __builtin_elementwise_fma(kap2, pr2[rp], tj2);
+                }
+                tj = (T)(tj2.x + tj2.y);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T kap = kappa_hot_end<T, KIND>(kp[r]);
+                    acc[r] = tfma<T>(kap, pj, acc[r]);
+                    tj = tfma<T>(kap, pr[r], tj);
+                }
             }
             t[jj] = tj;
             // Pin the accumulators at the end of every column: without this the optimizer sinks the 2*R accumulate
             // fmas of all 16 unrolled columns below the batch (64 kernel values kept live = 128 extra VGPRs), and the
             // scheduler hoists the scalar operand loads of all 16 columns (320 SGPRs, spills).
+            if (PACKED) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[r]));
+                for (int rp = 0; rp < RP; ++rp) asm volatile("" : "+v"(acc2[rp]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[r]));
+            }
             asm volatile("" : "+v"(t[jj]));
             __builtin_amdgcn_sched_barrier(0);
             aj = an;
@@ -152,6 +198,13 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
             if (lane < SYM_BATCH) Pcol[cslot * n + jb + lane] = FOLD ? v * wcol[row0 + jb + lane] : v;
         }
     }
+    if (PACKED) {  // the packed row sums continue unpacked in the tail / are stored below
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp) {
+            acc[2 * rp] = (T)acc2[rp].x;
+            acc[2 * rp + 1] = (T)acc2[rp].y;
+        }
+    }
     // ragged tail of the block (fewer than 16 columns): one column at a time, plain wave reduction
     for (int64_t jc = jfull; jc < j1; ++jc) {
         const int64_t j = row0 + jc;
@@ -165,7 +218,7 @@ __global__ __launch_bounds__(256) void kff_sym_kernel(const T* __restrict__ Xs, 
         for (int r = 0; r < R; ++r) {
             T gram = ai[r];
 #pragma unroll
-            for (int d = 0; d < DP; ++d) gram = tfma<T>(xi[r][d], xj[d], gram);
+            for (int d = 0; d < DP; ++d) gram = tfma<T>(PACKED ? (T)xi2[(r / 2) % RP][d][r % 2] : xi[r % RU][d], xj[d], gram);
             const T kap = kappa_hot_from_gram<T, KIND, CLAMP>(gram, aj, tab);  // FOLD: aj == 0, the weight is in pj / applied below
             acc[r] = tfma<T>(kap, pj, acc[r]);
             tj = tfma<T>(kap, pr[r], tj);
