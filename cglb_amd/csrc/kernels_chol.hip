@@ -74,15 +74,10 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(T* __restrict__ A, int n,
 }
 
 // Panel below the diagonal block: X L_kk^T = P, one row of P per thread in registers (fully unrolled).  L_kk comes from the
-// dense read-only copy Dblk, staged once per workgroup into LDS and read back with wave-uniform addresses (broadcast reads, dozens
-// in flight).  Scalar loads of the 2080 factors were tried first: with one wave per SIMD and ~100 SGPRs only three s_load_dwordx16
-// fit in flight, and the 171 `s_waitcnt lgkmcnt(0)` each exposed the scalar-cache latency: 31 us per launch.
+// dense read-only copy Dblk with wave-uniform indices, i.e. through scalar loads into SGPRs that feed the fma directly.
 // FULL: nb == 64 (every block but a ragged last one): loads and stores are fully static.
 template <typename T, bool FULL>
 __global__ __launch_bounds__(64) void chol_panel_kernel(T* __restrict__ A, int n, int k0, int nb, const T* __restrict__ Dblk) {
-    __shared__ T Dl[CHOL_NB * CHOL_NB + CHOL_NB];
-    for (int q = threadIdx.x; q < CHOL_NB * CHOL_NB + CHOL_NB; q += 64) Dl[q] = Dblk[q];
-    __syncthreads();
     const int row = k0 + nb + blockIdx.x * 64 + threadIdx.x;
     if (row >= n) return;
     T x[CHOL_NB];
@@ -103,9 +98,9 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(T* __restrict__ A, int n
     // step, so a lone wave has no dependent chain to wait on); column t of L_kk is contiguous in Dblk (stored transposed)
 #pragma unroll
     for (int t = 0; t < CHOL_NB; ++t) {
-        x[t] *= Dl[CHOL_NB * CHOL_NB + t];
+        x[t] *= Dblk[CHOL_NB * CHOL_NB + t];
 #pragma unroll
-        for (int cc = t + 1; cc < CHOL_NB; ++cc) x[cc] = tfma<T>(-x[t], Dl[t * CHOL_NB + cc], x[cc]);
+        for (int cc = t + 1; cc < CHOL_NB; ++cc) x[cc] = tfma<T>(-x[t], Dblk[t * CHOL_NB + cc], x[cc]);
     }
     if (FULL) {
 #pragma unroll
