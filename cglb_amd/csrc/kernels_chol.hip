@@ -6,7 +6,9 @@
 #include "devmath.h"
 #include "dispatch.h"
 
+#ifndef CHOL_NB
 #define CHOL_NB 64
+#endif
 
 __device__ __forceinline__ double readlane_t(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -64,13 +66,13 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(T* __restrict__ A, int n,
 #pragma unroll
     for (int cc = 0; cc < CHOL_NB; ++cc) {
         if (r < nb && cc <= r && cc < nb) A[(size_t)(k0 + cc) * n + k0 + r] = a[cc];
-        Dblk[cc * CHOL_NB + r] = (cc < r) ? a[cc] : T(0);  // strictly lower part, transposed: Dblk[t][c] = L[c][t]
+        if (r < CHOL_NB) Dblk[cc * CHOL_NB + r] = (cc < r) ? a[cc] : T(0);  // strictly lower part, transposed: Dblk[t][c] = L[c][t]
     }
     T diag = T(1);
 #pragma unroll
     for (int cc = 0; cc < CHOL_NB; ++cc)
         if (cc == r) diag = a[cc];
-    Dblk[CHOL_NB * CHOL_NB + r] = T(1) / diag;
+    if (r < CHOL_NB) Dblk[CHOL_NB * CHOL_NB + r] = T(1) / diag;
 }
 
 // Panel below the diagonal block: X L_kk^T = P, one row of P per thread in registers (fully unrolled).  L_kk comes from the
