@@ -127,3 +127,28 @@ def test_cyclic_symmetric_driver_matches_single_process(name, world):
     assert bound == pytest.approx(refg.bound, rel=1e-12)
     packed = np.concatenate([refg.grad["lengthscales"], [refg.grad["variance"], refg.grad["noise"], refg.grad["mean"]], refg.grad["Z"].reshape(-1)])
     np.testing.assert_allclose(grad, packed, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(packed).max()))
+
+
+@pytest.mark.parametrize("name,max_error", [("rbf_d8_trained", None), ("rbf_d8_init", 50.0), ("rbf_d8_maxiter", None), ("rbf_d8_warm", None)])
+def test_cyclic_driver_lookahead_does_not_change_results(name, max_error):
+    """The cyclic driver enqueues the next mat-vec before it has seen the stop-test scalar while the residual is far above the
+    tolerance; with and without that look-ahead the solve must give identical steps, residual and v (single process, oracle ops:
+    the control flow is what is under test).  `rbf_d8_init` with a loose tolerance ends on a mispredicted (wasted) mat-vec."""
+    from cglb_amd.distributed import Comm, SymShardedCGLB
+    from sharded_oracle_ops import OracleSymLocalOps
+    g = load_golden(name)
+    hyp = golden_hypers(g)
+    N = g["X"].shape[0]
+    me = float(g["max_error"]) if max_error is None else max_error
+    out = []
+    for look in (False, True):
+        drv = SymShardedCGLB(OracleSymLocalOps(int(g["kind"]), g["X"], g["y"], hyp, 0, N), Comm())
+        drv.lookahead = look
+        drv.v.copy_(torch.from_numpy(g["v0"]))
+        drv.setup()
+        steps, half = drv.pcg(me, int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+        out.append((steps, half, drv.v_full().numpy().copy()))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2])
+    if max_error is None:
+        assert abs(out[0][0] - int(g["steps"])) <= (0 if int(g["steps"]) <= 40 else 1)
