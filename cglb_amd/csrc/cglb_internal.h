@@ -64,6 +64,7 @@ struct cglb_ctx {
     size_t k1_events_used = 0;
     double k1_ms_total = 0.0;
     long long k1_launches = 0;
+    int aat_block = 512;  // block width of the lower-triangle-only split-K A A^T (0 or not dividing M: the full square)
     int sym_order = 1, sym_order_built = -1;  // item order of the symmetric kernel: 0 row-block major, 1 XCD-aware (kernels_kff_sym.hip)
     int sym_rbrows = 0, sym_nitems = 0, sym_world = 1, sym_rank = 0;
     int par_world = 1, par_rank = 0;  // cyclic distribution of the symmetric K_ff work over ranks (cglb_set_parallel)

@@ -7,6 +7,8 @@ X, y, Z = synthetic_problem(100000, 8, 1024, 0)
 h = trained_like_hypers(8)
 ctx = HipContext(X, y, 1024, "rbf")
 ctx.set_option("chol_mode", int(os.environ.get("CHOL", "1")))
+if "AAT_BLOCK" in os.environ:
+    ctx.set_option("aat_block", int(os.environ["AAT_BLOCK"]))
 ctx.set_hypers(h["lengthscales"], h["variance"], h["noise"], h["mean"], Z, 1e-6)
 for _ in range(3):
     ctx.setup()
