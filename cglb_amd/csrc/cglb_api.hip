@@ -470,7 +470,7 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     CR(dalloc(c, &c->Xs, N * Dp * e)); CR(dalloc(c, &c->xa, N * e)); CR(dalloc(c, &c->Zs, M * Dp * e)); CR(dalloc(c, &c->za, M * e));
     CR(dalloc(c, &c->Zh, M * Dp * e)); CR(dalloc(c, &c->zah, M * e)); CR(dalloc(c, &c->Linv, M * M * e)); CR(dalloc(c, &c->LinvT, M * M * e));
     CR(dalloc(c, &c->w_q, M * e));
-    CR(dalloc(c, &c->Xh, N * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, &c->wh, N * e)); CR(dalloc(c, &c->pwh, N * e)); CR(dalloc(c, (void**)&c->exp_tab, CGLB_TAB_SIZE * sizeof(double)));
+    CR(dalloc(c, &c->Xh, N * Dp * e)); CR(dalloc(c, &c->Xhsq, N * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, &c->wh, N * e)); CR(dalloc(c, &c->pwh, N * e)); CR(dalloc(c, (void**)&c->exp_tab, CGLB_TAB_SIZE * sizeof(double)));
     {
         std::vector<double> tab(CGLB_TAB_SIZE);
         for (int k = 0; k < CGLB_TAB_SIZE; ++k) {
@@ -509,7 +509,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     if (!c) return CGLB_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->xah, c->wh, c->pwh, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
+    void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->Xhsq, c->xah, c->wh, c->pwh, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
                     c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -530,6 +530,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "pcg_lookahead")) c->pcg_lookahead = (int)value;
     else if (!strcmp(name, "sym_order")) c->sym_order = (int)value;
     else if (!strcmp(name, "aat_block")) c->aat_block = (int)value;
+    else if (!strcmp(name, "grad_gram")) c->grad_gram = (int)value;
     else if (!strcmp(name, "k1_profile")) {  // 1: start timing every launch of the symmetric pair kernel (counters reset), 0: stop
         if (value) { c->k1_events_used = 0; c->k1_ms_total = 0.0; c->k1_launches = 0; }
         else CGLB_TRY(k1_profile_collect(c));
@@ -592,6 +593,7 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xh, c->xah, true));
     CGLB_TRY(launch_hot_weights(c));
+    CGLB_TRY(launch_hot_squares(c));
     CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zs, c->za));
     CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zh, c->zah, true));
     CGLB_TRY(launch_frag_prep(c));

@@ -40,6 +40,7 @@ struct cglb_ctx {
     void* chol_blk = nullptr;            // dense copy of the current diagonal block + reciprocal diagonal (kernels_chol.hip)
     int chol_mode = 1;                   // 1: blocked LDS Cholesky (kernels_chol.hip), 0: rocSOLVER potrf
     int precond_mode = 0;                // 0: stored panel A (reference form), 1: implicit K_uf products
+    void *Xhsq = nullptr;  // Xh squared element-wise: second-moment operand of the Gram-form gradient pass (kernels_grad.hip)
     void *wh = nullptr, *pwh = nullptr;  // RBF column weights 2^(xah_j/T) and the weighted operand p_j * wh_j of the symmetric mat-vec (length N)
     void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/T octave, T = 2^CGLB_TAB_BITS (devmath.h exp2_tab)
     double* exp_tab = nullptr;           // device table 2^(k/64), k < 64
@@ -64,6 +65,7 @@ struct cglb_ctx {
     size_t k1_events_used = 0;
     double k1_ms_total = 0.0;
     long long k1_launches = 0;
+    int grad_gram = 1;    // 1: Gram-form symmetric gradient pass (moments), 0: direct differences
     int aat_block = 512;  // block width of the lower-triangle-only split-K A A^T (0 or not dividing M: the full square)
     int sym_order = 1, sym_order_built = -1;  // item order of the symmetric kernel: 0 row-block major, 1 XCD-aware (kernels_kff_sym.hip)
     int sym_rbrows = 0, sym_nitems = 0, sym_world = 1, sym_rank = 0;
@@ -145,6 +147,7 @@ int launch_cholesky_lower(cglb_ctx* c, void* A, int* info_slot);
 int launch_frag_prep(cglb_ctx* c);
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
 int launch_hot_weights(cglb_ctx* c);
+int launch_hot_squares(cglb_ctx* c);  // Xhsq = Xh .* Xh after set_hypers
 int k1_profile_collect(cglb_ctx* c);  // resolves the pending event pairs into k1_ms_total / k1_launches  // wh = 2^(xah/T) after set_hypers (RBF)
 int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial);  // this rank's share of the global upper triangle
 int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, double* out_dl);

@@ -80,6 +80,105 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
     }
 }
 
+// Gram-form variant of the symmetric N^2 pass (SYM only, unclamped exponent range - the common case; selected by launch_grad_kff*):
+// the pair value comes from the Gram chain seeded with the row norm exactly as in the mat-vec (D fma + 1 instead of D sub, D mul,
+// D add), and the per-dimension sums are built from moments,
+//   sum_j hv_ij (x_id - x_jd)^2 = x_id^2 S0_i - 2 x_id S1_id + S2_id,   S0 = sum hv, S1_d = sum hv x_jd, S2_d = sum hv x_jd^2,
+// with x_jd and x_jd^2 both wave-uniform scalar operands: 2 D + 1 accumulate instructions per pair as before, ~38 instead of 46 in all.
+// The expansion cancels when |x_d| >> |x_id - x_jd| for the pairs that carry weight (lengthscale far below the data range): the
+// operands are centred, so the loss is ~log10((range / l)^2) of 16 digits - irrelevant against the 1e-8 the optimiser needs.
+template <typename T, int KIND, int DP, int R>
+__global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict__ Xh, const T* __restrict__ Xhsq, const T* __restrict__ ah,
+                                                            const T* __restrict__ u, const T* __restrict__ v, int64_t row0, int64_t n,
+                                                            int64_t jchunk, int64_t blk0, int rb_stride, int rb_offset,
+                                                            double* __restrict__ part, const double* __restrict__ exp_tab) {
+    __shared__ double smem[16];
+    __shared__ double tab[CGLB_TAB_SIZE];
+    load_exp_table(tab, exp_tab);
+    const int64_t rblock = ((int64_t)blockIdx.x * rb_stride + rb_offset) * (256 * R);  // cyclic over ranks when rb_stride > 1
+    const int64_t rbase = rblock + threadIdx.x;
+    T xi[R][DP], S1[R][DP], S2[R][DP], S0[R], aseed[R], ui[R], vi[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int64_t row = rbase + (int64_t)k * 256;
+        const int64_t rr = row < n ? row : n - 1;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            xi[k][d] = Xh[(row0 + rr) * DP + d];
+            S1[k][d] = 0;
+            S2[k][d] = 0;
+        }
+        S0[k] = 0;
+        const T a = ah[row0 + rr];
+        aseed[k] = (KIND == CGLB_RBF) ? a : T(-0.5) * a;
+        ui[k] = row < n ? u[row0 + rr] : T(0);  // padded rows carry zero weight
+        vi[k] = row < n ? v[row0 + rr] : T(0);
+    }
+    int64_t j0 = (int64_t)blockIdx.y * jchunk;
+    const int64_t j1 = (j0 + jchunk < n) ? j0 + jchunk : n;
+    const int64_t sym_from = rblock + 256 * R;
+    if (j0 < rblock) j0 = rblock;
+    for (int64_t jc = j0; jc < j1; ++jc) {
+        const int64_t j = row0 + jc;
+        const T vj = v[j];
+        const T wu = (jc >= sym_from) ? u[j] : T(0);  // wave-uniform
+        const T aj = ah[j];
+        T xj[DP], sj[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            xj[d] = Xh[j * DP + d];
+            sj[d] = Xhsq[j * DP + d];
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            T g = aseed[k];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) g = tfma<T>(xi[k][d], xj[d], g);
+            T h;
+            if (KIND == CGLB_RBF) {
+                h = exp2_tab<false>(g + aj, tab);
+            } else {
+                const T d2 = tfma<T>(T(-2), g, aj);
+                h = T(3) * exp2_tab<false>(-sqrt_hot(d2), tab);
+            }
+            T w = ui[k] * vj;
+            w = tfma<T>(vi[k], wu, w);
+            const T hv = h * w;
+            S0[k] += hv;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                S1[k][d] = tfma<T>(hv, xj[d], S1[k][d]);
+                S2[k][d] = tfma<T>(hv, sj[d], S2[k][d]);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double x = (double)xi[k][d];
+            s += x * (x * (double)S0[k] - 2.0 * (double)S1[k][d]) + (double)S2[k][d];
+        }
+        s = block_sum(s, smem);
+        if (threadIdx.x == 0) part[(blk0 + (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * DP + d] = s;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void square_kernel(const T* __restrict__ x, int64_t n, T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] * x[i];
+}
+// Xhsq = Xh .* Xh (after set_hypers): the second-moment operand of the Gram-form gradient pass
+int launch_hot_squares(cglb_ctx* c) {
+    const int64_t tot = c->N * c->Dp;
+    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((square_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, (const T*)c->Xh,
+                                                 tot, (T*)c->Xhsq));
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
 // out[d] += scale[d] * sum_b part[b*DP + d]   (one block per d)
 __global__ __launch_bounds__(256) void grad_dl_finalize_kernel(const double* __restrict__ part, int64_t nblk, int DP, int D,
                                                                ScaleParams sp, double var, double* __restrict__ out, int accumulate) {
@@ -145,8 +244,16 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
     hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, SYMV>), grid, dim3(256), 0, c->stream, (const T*)c->Xh + c->r0 * DP,        \
                        (const T*)u_local, (const T*)v_full + c->r0, c->nloc, (const T*)c->Xh + r.col0 * DP, (const T*)v_full + r.col0, \
                        (const T*)u_local, r.ncols, r.jchunk, blk0, 1, 0, c->gpart, (const double*)c->exp_tab)
-        if (r.sym) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); }); }
+#define GG_LAUNCH(RR)                                                                                                                 \
+    hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,           \
+                       (const T*)c->xah, (const T*)u_local - c->r0, (const T*)v_full, c->r0, c->nloc, r.jchunk, blk0, 1, 0, c->gpart,     \
+                       (const double*)c->exp_tab)
+        if (r.sym && c->grad_gram && !c->exp_clamp) {
+            // u_local is indexed by global row inside the kernel (row0 + local), hence the shifted base pointer
+            CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GG_LAUNCH(2); } else { GG_LAUNCH(1); });
+        } else if (r.sym) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); }); }
         else { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); }); }
+#undef GG_LAUNCH
 #undef GK_LAUNCH
         CGLB_LAUNCH_CHECK(c);
         blk0 += bx * r.jsplit;
@@ -186,7 +293,13 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
     hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, true>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)u_full,  \
                        (const T*)v_full, c->N, (const T*)c->Xh, (const T*)v_full, (const T*)u_full, c->N, jchunk, (int64_t)0,       \
                        c->par_world, c->par_rank, c->gpart, (const double*)c->exp_tab)
-    CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); });
+#define GGC_LAUNCH(RR)                                                                                                               \
+    hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,          \
+                       (const T*)c->xah, (const T*)u_full, (const T*)v_full, (int64_t)0, c->N, jchunk, (int64_t)0, c->par_world, c->par_rank, \
+                       c->gpart, (const double*)c->exp_tab)
+    if (c->grad_gram && !c->exp_clamp) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GGC_LAUNCH(2); } else { GGC_LAUNCH(1); }); }
+    else { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); }); }
+#undef GGC_LAUNCH
 #undef GKC_LAUNCH
     CGLB_LAUNCH_CHECK(c);
     hipLaunchKernelGGL(grad_dl_finalize_kernel, dim3(c->D), dim3(256), 0, c->stream, (const double*)c->gpart, nblk, c->Dp, c->D, sp,

@@ -136,3 +136,31 @@ def test_in_situ_kernel_timing_counts_every_matvec_of_a_solve():
         ctx.get_stat("no_such_statistic")
     ctx.matvec(torch.from_numpy(g["y"]))  # not profiled any more
     assert ctx.get_stat("k1_launches") == launches
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+@pytest.mark.parametrize("ls", [1.0, 0.1, 0.03])
+def test_gram_form_gradient_pass_against_direct_differences_and_oracle(kind, ls):
+    """The symmetric N^2 gradient pass builds sum_j hv (x_id - x_jd)^2 from moments (x^2 S0 - 2 x S1 + S2), which cancels when the
+    lengthscale is far below the data range (here range/l up to ~200: ~4.5 of 16 digits).  Both forms of the pass and the oracle
+    must agree on the lengthscale gradient well inside what the optimiser needs."""
+    from cglb_amd.hip_context import HipContext
+    N, D, M = 1200, 3, 16
+    rng = np.random.default_rng(17)
+    X = rng.uniform(-3.0, 3.0, size=(N, D))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(N)
+    Z = X[:M].copy()
+    hyp = orc.Hypers(np.full(D, ls), 1.3, 0.2, 0.1, Z, 1e-6)
+    v = rng.standard_normal(N) * 0.1
+    ref = orc.objective(kind, X, y, hyp, v, run_cg=False, with_grad=True)
+    got = []
+    for gram in (0, 1):
+        ctx = HipContext(X, y, M, kind)
+        ctx.set_option("grad_gram", gram)
+        ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+        vd = torch.from_numpy(v).to(ctx.device)
+        res = ctx.objective_and_grad(vd, False)
+        assert res.bound == pytest.approx(ref.bound, rel=1e-11)
+        got.append(res.grad["lengthscales"])
+        np.testing.assert_allclose(res.grad["lengthscales"], ref.grad["lengthscales"], rtol=2e-8, atol=1e-9 * np.abs(ref.grad["lengthscales"]).max())
+    np.testing.assert_allclose(got[1], got[0], rtol=1e-9, atol=1e-11 * np.abs(got[0]).max())
