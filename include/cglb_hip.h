@@ -178,7 +178,7 @@ int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
  * kernel (in mat-vecs, solves and evaluations alike) is bracketed by HIP events on the context stream; "k1_ms_total" and
  * "k1_launches" return the accumulated device time and launch count since then (the call synchronises with the pending launches). */
 int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
-/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" | "sym_order" | "k1_profile" ...;
+/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" | "sym_order" | "aat_block" | "grad_gram" | "k1_profile" ...;
  * returns CGLB_ERR_BAD_ARG if unknown. */
 int cglb_set_option(cglb_ctx* ctx, const char* name, int64_t value);
 
