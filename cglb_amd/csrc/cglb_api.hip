@@ -690,7 +690,7 @@ int cglb_shard_precond_u(cglb_ctx* c, const void* r_local, void* u_partial) {
     return precond_u_any(c, r_local, u_partial);
 }
 int cglb_shard_precond_z(cglb_ctx* c, const void* r_local, const void* u, void* z_local, void* rz_partial) {
-    if (!c || !r_local || !u || !z_local || !rz_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    if (!c || !r_local || !u || !z_local) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;  // rz_partial may be NULL
     CGLB_TRY(require_terms(c));
     HIP_CHECK(c, hipSetDevice(c->device));
     CGLB_TRY(launch_tri_apply(c, u, c->w_t));

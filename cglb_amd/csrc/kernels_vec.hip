@@ -321,8 +321,10 @@ int launch_precond_z_from(cglb_ctx* c, const void* r_local, const void* Ks_local
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((precond_z_kernel<T>), dim3(g2), dim3(256), 0, c->stream, (const T*)r_local,
                                                  (const T*)Ks_local, 1, c->nloc, (T)(1.0 / c->noise), (T*)z_local, c->dotpart));
     CGLB_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(finalize_sum_kernel2, dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, g2, rz_slot, 1.0 / c->noise);
-    CGLB_LAUNCH_CHECK(c);
+    if (rz_slot) {  // callers that form r^T z themselves (cyclic multi-GPU driver) pass no slot
+        hipLaunchKernelGGL(finalize_sum_kernel2, dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, g2, rz_slot, 1.0 / c->noise);
+        CGLB_LAUNCH_CHECK(c);
+    }
     return CGLB_OK;
 }
 
@@ -339,8 +341,10 @@ int launch_precond_z(cglb_ctx* c, const void* r_local, const void* t, void* z_lo
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((precond_z_kernel<T>), dim3(g2), dim3(256), 0, c->stream, (const T*)r_local,
                                                  (const T*)c->tpart, msplit, c->nloc, (T)(1.0 / c->noise), (T*)z_local, c->dotpart));
     CGLB_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(finalize_sum_kernel2, dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, g2, rz_slot, 1.0 / c->noise);
-    CGLB_LAUNCH_CHECK(c);
+    if (rz_slot) {  // callers that form r^T z themselves (cyclic multi-GPU driver) pass no slot
+        hipLaunchKernelGGL(finalize_sum_kernel2, dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, g2, rz_slot, 1.0 / c->noise);
+        CGLB_LAUNCH_CHECK(c);
+    }
     return CGLB_OK;
 }
 

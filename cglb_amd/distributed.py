@@ -109,7 +109,7 @@ class HipLocalOps(LocalOps):
     @staticmethod
     def _p(t):
         from ctypes import c_void_p
-        return c_void_p(t.data_ptr())
+        return None if t is None else c_void_p(t.data_ptr())
 
     def _ck(self, rc):
         self._lib.check(rc, self.h)
@@ -366,7 +366,7 @@ class SymShardedCGLB:
         r_loc = self.r[self.r0:self.r1]
         ops.precond_u(r_loc, self.u)
         self.comm.allreduce(self.u)
-        ops.precond_z(r_loc, self.u, self._own(self.zbuf), self.scratch)
+        ops.precond_z(r_loc, self.u, self._own(self.zbuf), None)   # r^T z is formed below over the gathered z (no scalar collective)
         self.comm.allgather_inplace(self.zbuf, self.per)
         ops.vec_dot(self.N, self.r, self.zbuf[: self.N], rz_out)
 

@@ -88,7 +88,7 @@ int cglb_precond_apply(cglb_ctx* ctx, const void* r, void* z, double* rz);
 /* sharded: u_partial[m] = A_loc r_loc (host all-reduces u), then z_loc and the partial sum of rz. */
 int cglb_shard_precond_u(cglb_ctx* ctx, const void* r_local, void* u_partial /* dev [m] */);
 int cglb_shard_precond_z(cglb_ctx* ctx, const void* r_local, const void* u /* dev [m], reduced */,
-                         void* z_local, void* rz_partial /* dev [1] */);
+                         void* z_local, void* rz_partial /* dev [1], or NULL when the caller forms r^T z itself */);
 
 /* ---- vector primitives of the PCG loop (conjugate_gradient.py:67-75), for the sharded host loop ---- */
 /* dot: out[0] = sum_i a_i b_i over local rows (dev scalar, deterministic order). */

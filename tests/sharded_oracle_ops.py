@@ -51,7 +51,8 @@ class OracleLocalOps(LocalOps):
     def precond_z(self, r, u, z, rz):
         rp = r.numpy() - self._t(u) @ self.A
         z.copy_(torch.from_numpy(rp / self.hyp.noise))
-        rz[0] = float(rp @ r.numpy()) / self.hyp.noise
+        if rz is not None:
+            rz[0] = float(rp @ r.numpy()) / self.hyp.noise
     def update_v_r(self, v, r, p, Ap, rz, pAp, update_r):
         gamma = float(rz[0]) / float(pAp[0])
         v += gamma * p
