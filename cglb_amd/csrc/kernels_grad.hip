@@ -248,7 +248,7 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
     hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,           \
                        (const T*)c->xah, (const T*)u_local - c->r0, (const T*)v_full, c->r0, c->nloc, r.jchunk, blk0, 1, 0, c->gpart,     \
                        (const double*)c->exp_tab)
-        if (r.sym && c->grad_gram && !c->exp_clamp) {
+        if (r.sym && c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64) {  // fp32 keeps direct differences: no digits to spare
             // u_local is indexed by global row inside the kernel (row0 + local), hence the shifted base pointer
             CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GG_LAUNCH(2); } else { GG_LAUNCH(1); });
         } else if (r.sym) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); }); }
@@ -297,7 +297,7 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
     hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,          \
                        (const T*)c->xah, (const T*)u_full, (const T*)v_full, (int64_t)0, c->N, jchunk, (int64_t)0, c->par_world, c->par_rank, \
                        c->gpart, (const double*)c->exp_tab)
-    if (c->grad_gram && !c->exp_clamp) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GGC_LAUNCH(2); } else { GGC_LAUNCH(1); }); }
+    if (c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GGC_LAUNCH(2); } else { GGC_LAUNCH(1); }); }
     else { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); }); }
 #undef GGC_LAUNCH
 #undef GKC_LAUNCH
