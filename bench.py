@@ -79,6 +79,28 @@ def cpu_baseline(kind, X, y, Z, hyp, N, D, M, steps_cg, restarts):
     }
 
 
+def check_against_fixture(N, D, M, kind, hyp_name, res, steps=None, bound=None):
+    """Compare steps / bound of a cold-start evaluation with tests/golden/headline/*.npz (data, not oracle code).  north_star: 1e-6
+    relative on the bound; step count exact up to 40 steps, +-1 beyond (DESIGN.md section 6 note).  Raises on a mismatch."""
+    name = {("rbf", "trained"): "headline_rbf_trained", ("rbf", "init"): "headline_rbf_init", ("matern32", "trained"): "headline_m32_trained"}
+    path = os.path.join(ROOT, "tests", "golden", "headline", name.get((kind, hyp_name), "none") + ".npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if (int(g["N"]), int(g["D"]), int(g["M"])) != (N, D, M):
+        return None
+    steps = res.steps if res is not None else steps
+    bound = res.bound if res is not None else bound
+    ref_steps, ref_bound = int(g["steps"]), float(g["bound"])
+    rel = abs(bound - ref_bound) / abs(ref_bound)
+    ok = abs(steps - ref_steps) <= (0 if ref_steps <= 40 else 1) and rel <= 1e-6
+    out = {"fixture": os.path.relpath(path, ROOT), "ref_steps": ref_steps, "steps": steps, "ref_bound": ref_bound, "bound": bound,
+           "bound_rel_err": rel, "ok": bool(ok)}
+    if not ok:
+        raise SystemExit(f"bench.py: result disagrees with the reference-solver fixture: {out}")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,7 +221,8 @@ def main():
             torch.cuda.synchronize(dev)
             dtm = (time.perf_counter() - t0) / 2
             secondary["matern32"] = {"workload_hypers": args.hypers, "value": 1.0 / dtm, "unit": "evals/s", "ms_per_step": dtm * 1e3,
-                                     "cg_steps": resm.steps, "bound": resm.bound, "kff_matvec_ms": ctx_m.time_kernel(0, 5)}
+                                     "cg_steps": resm.steps, "bound": resm.bound, "kff_matvec_ms": ctx_m.time_kernel(0, 5),
+                                     "k1_ms": ctx_m.time_kernel(3, 5)}
             ctx_m.close()
             del ctx_m, vm
 
@@ -216,36 +239,83 @@ def main():
     ms_pair_standalone = ctx.time_kernel(3 if world == 1 else 4, reps)
     ms_prec = ctx.time_kernel(1, reps)   # preconditioner apply (gemv_u + triangular products + gemv_t + epilogue)
     nloc = parts[rank][1] - parts[rank][0]
-    # algorithmic pairs of one launch of the dominant kernel on this rank: all N^2 of K_ff on one GPU, N^2 / world with the
-    # cyclic-symmetric split
-    flops = pair_flops(kind, D) * float(N) * float(N) / world
-    achieved = flops / (ms_pair * 1e-3) / 1e12
+    # Work of ONE launch of the pair kernel = (flops per pair evaluation) x (pairs the launch evaluates).  The kernel is
+    # the symmetric form: each unordered pair {i, j} is evaluated once and used for out_i and out_j, so a launch evaluates
+    # ~N(N + 256)/2 pairs on one GPU (the library reports the exact count of its work list), not N^2.
+    pairs_eval = ctx.get_stat("k1_pairs_per_launch")
+    fpp = pair_flops(kind, D)
+    achieved = fpp * pairs_eval / (ms_pair * 1e-3) / 1e12
     esz = 8
     prec_bytes = 2.0 * M * nloc * esz + 3.0 * nloc * esz
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE);
-    # only quoted for the workload it was collected on (single GPU, headline size)
-    traffic_k1 = traffic_prec = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if world == 1 and (N, D, M, kind) == (100_000, 8, 1024, "rbf") and os.path.exists(pmc_file):
-        pk = json.load(open(pmc_file))["kernels"]
+    # Counter-derived figures come from committed rocprofv3 --pmc passes of this same command (tools/pmc_collect.sh); they are
+    # quoted only for the workload they were collected on and name their source file.
+    traffic_k1 = traffic_prec = executed = None
+    pmc_hbm = os.path.join("profiles", "r02_pmc_hbm_traffic.json")
+    pmc_sq = os.path.join("profiles", "r02_pmc_sq_counters.json")
+    on_profiled_workload = world == 1 and (N, D, M, kind) == (100_000, 8, 1024, "rbf")
+    if on_profiled_workload and os.path.exists(os.path.join(ROOT, pmc_hbm)):
+        pk = json.load(open(os.path.join(ROOT, pmc_hbm)))["kernels"]
         traffic_k1 = pk["kff_sym_kernel"]["hbm_bytes_per_launch"]
-        traffic_prec = sum(pk[k]["hbm_bytes_per_launch"] for k in ("gemv_u_kernel", "gemv_t_kernel", "precond_z_kernel"))
+        traffic_prec = sum(pk[k]["hbm_bytes_per_launch"] for k in ("gemv_u_kernel", "gemv_t_kernel", "precond_z_kernel") if k in pk)
+    if on_profiled_workload and os.path.exists(os.path.join(ROOT, pmc_sq)):
+        sq = json.load(open(os.path.join(ROOT, pmc_sq)))["kernels"].get("kff_sym_kernel", {})
+        if "executed_flop_per_launch" in sq:
+            executed = {"flop_per_launch": sq["executed_flop_per_launch"],
+                        "tflops": sq["executed_flop_per_launch"] / (ms_pair * 1e-3) / 1e12,
+                        "frac_of_peak": sq["executed_flop_per_launch"] / (ms_pair * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                        "valu_wave_instructions_per_launch": sq.get("valu_insts_per_launch"),
+                        # every fp64 / VOP3 instruction occupies its SIMD for 4 cycles: issue cycles per SIMD / launch time = the clock
+                        # the kernel would need if it did nothing but issue -> ~the sustained clock means the issue pipe is full
+                        "valu_issue_ghz_needed": (sq.get("valu_insts_per_launch", 0.0) * 4.0 / 1024.0) / (ms_pair * 1e-3) / 1e9,
+                        "source": pmc_sq}
     roofline = {
         "kernel": "kff_sym_kernel (pair kernel of the implicit K_ff mat-vec)", "bound": "valu_fp64", "achieved": achieved,
-        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_k1,
+        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+        "traffic": traffic_k1, "traffic_source": pmc_hbm if traffic_k1 is not None else None,
         "ms_per_launch": ms_pair, "launches_timed": int(k1_launches), "ms_per_launch_standalone": ms_pair_standalone,
-        "note": ("frac can exceed 1: the symmetric kernel uses every kernel value for two outputs, so it executes about 10 fp64 instructions "
-                 "per algorithmic pair where the 28-flop count assumes 28; its executed instruction stream (1.71e9 VALU wave-instructions per "
-                 "launch at N=100k, profiles/r01_pmc_sq_counters.json) is issue-bound at the sustained fp64 clock, see DESIGN.md section 4"),
-        "algorithmic": (f"{pair_flops(kind, D)} flop/pair x N x n_local pairs per launch; K_ff is never materialised, algorithmic HBM bytes "
-                        f"N(D+2)w = {N * (D + 2) * 8 / 1e6:.1f} MB; the symmetric kernel evaluates each pair of the square block once"),
+        "pairs_evaluated_per_launch": pairs_eval, "flop_per_pair": fpp,
+        # time of a non-symmetric kernel doing all N^2/world pairs at the vector-fp64 peak, over the measured time: how the launch
+        # compares with SURVEY 8(d)'s floor for this mat-vec (NOT a fraction of peak; > 1 is the gain of the symmetric form)
+        "vs_nonsymmetric_floor": (fpp * float(N) * float(N) / world / (FP64_VECTOR_PEAK_TFLOPS * 1e12)) / (ms_pair * 1e-3),
+        "executed": executed,
+        "algorithmic": (f"{fpp} flop/pair x {pairs_eval:.4g} evaluated pairs per launch (symmetric form: each unordered pair once); K_ff is never "
+                        f"materialised, algorithmic HBM bytes N(D+2)w = {N * (D + 2) * 8 / 1e6:.1f} MB"),
     }
+    assert 0.0 < roofline["frac"] <= 1.0, roofline
     roofline_hbm = {
         "kernel": "nystrom preconditioner apply (gemv_u_kernel + gemv_t_kernel over the stored panel A + precond_z_kernel)", "bound": "hbm",
         "achieved": prec_bytes / (ms_prec * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": prec_bytes / (ms_prec * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_prec, "ms_per_apply": ms_prec,
+        "frac": prec_bytes / (ms_prec * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_prec,
+        "traffic_source": pmc_hbm if traffic_prec is not None else None, "ms_per_apply": ms_prec,
         "algorithmic": "2 M n_local w + 3 n_local w bytes per apply",
     }
+    assert 0.0 < roofline_hbm["frac"] <= 1.0, roofline_hbm
+    # gradient bilinear pass ((5D+6) flop per pair), same symmetric enumeration of the pairs
+    roofline_grad = None
+    if world == 1:
+        ms_grad = ctx.time_kernel(2, 5)
+        gflop = (5 * D + 6) * pairs_eval
+        roofline_grad = {"kernel": "grad_kff_gram_kernel (N^2 bilinear form of the lengthscale gradient)", "bound": "valu_fp64",
+                         "achieved": gflop / (ms_grad * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": gflop / (ms_grad * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms_grad,
+                         "algorithmic": f"{5 * D + 6} flop/pair x {pairs_eval:.4g} evaluated pairs (stand-alone launches)"}
+        assert 0.0 < roofline_grad["frac"] <= 1.0, roofline_grad
+    if secondary and "matern32" in secondary:
+        mm = secondary["matern32"]
+        mflop = pair_flops("matern32", D) * pairs_eval
+        mm["roofline"] = {"kernel": "kff_sym_kernel<matern32>", "bound": "valu_fp64", "achieved": mflop / (mm["k1_ms"] * 1e-3) / 1e12,
+                          "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": mflop / (mm["k1_ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "ms_per_launch": mm["k1_ms"],
+                          "algorithmic": f"{pair_flops('matern32', D)} flop/pair x {pairs_eval:.4g} evaluated pairs (stand-alone launches)"}
+        assert 0.0 < mm["roofline"]["frac"] <= 1.0, mm["roofline"]
+
+    # ---- self-check of the timed result against the committed headline fixture (made by the reference's own solver loop over the
+    # blocked C operator, oracle/gen_headline_fixture.py): a numerically broken kernel must not produce a bench line
+    parity = check_against_fixture(N, D, M, kind, args.hypers, res)
+    if secondary is not None and parity is not None:
+        other_fx = check_against_fixture(N, D, M, kind, secondary["workload_hypers"], None, steps=secondary["cg_steps"], bound=secondary["bound"])
+        if other_fx is not None:
+            parity["secondary"] = other_fx
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -263,7 +333,8 @@ def main():
                 "cg": cg, "parallelism": f"cyclic-symmetric K_ff blocks + column-sharded Nystrom panel x{world}" if world > 1 else "single GPU",
             },
             "cg_steps": res.steps, "cg_residual_error": res.residual_error, "bound": res.bound,
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu, "secondary": secondary,
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_grad": roofline_grad, "cpu_baseline": cpu, "secondary": secondary,
+            "parity_check": parity,
         }
         print(json.dumps(record))
     if use_dist:

@@ -43,7 +43,7 @@ struct cglb_ctx {
     void *Xhsq = nullptr;  // Xh squared element-wise: second-moment operand of the Gram-form gradient pass (kernels_grad.hip)
     void *wh = nullptr, *pwh = nullptr;  // RBF column weights 2^(xah_j/T) and the weighted operand p_j * wh_j of the symmetric mat-vec (length N)
     void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/T octave, T = 2^CGLB_TAB_BITS (devmath.h exp2_tab)
-    double* exp_tab = nullptr;           // device table 2^(k/64), k < 64
+    double* exp_tab = nullptr;           // device table 2^(k/T) or 2^((k+1/2)/T) (CGLB_EXP_FLOOR), k < T = 2^CGLB_TAB_BITS, exponent pre-compensated (devmath.h)
     // common terms (column-major M x M unless noted)
     void* At = nullptr;      // A as [M][nloc] row-major == (nloc x M) column-major, ld = nloc
     void* Lc = nullptr;      // chol(Kuu + jitter I), lower, column-major
@@ -58,6 +58,7 @@ struct cglb_ctx {
     size_t frag_cap = 0;
     void* sym_items = nullptr;       // work list (row block, column chunk) of the symmetric mat-vec
     int64_t sym_n = -1, sym_chunk = 0, sym_chunk_opt = 0;
+    double sym_pairs = 0.0;          // kernel pairs one launch of the symmetric pair kernel evaluates (current item list)
     // in-situ timing of the dominant kernel (cglb_set_option "k1_profile", cglb_get_stat): HIP event pairs around every launch of the
     // symmetric pair kernel on the context stream, resolved lazily
     bool k1_profile = false;

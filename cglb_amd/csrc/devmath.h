@@ -73,6 +73,12 @@ __device__ __forceinline__ float sqrt_pos(float x) { return __builtin_sqrtf(fmax
 
 // Hot-loop variant for a squared distance that may come out slightly negative (Gram form): the clamp to a tiny positive
 // number replaces both the max(.,0) and the x > 0 select; sqrt_hot(d2 <= 0) = 1e-140, which the Matern profile maps to 1.
+// CGLB_SQRT_STEPS == 2: Goldschmidt step + residual correction (error ~ e0^3, below the rounding of the last fma; 8 + 4 issue slots).
+// CGLB_SQRT_STEPS == 1: the Goldschmidt step alone: relative error <= 1.5 e0^2 = 2.1e-14 with the 2^-23 seed of v_rsq_f64
+//                       (6 + 4 issue slots) - the "fast" precision level, see DESIGN.md section 4.
+#ifndef CGLB_SQRT_STEPS
+#define CGLB_SQRT_STEPS 1
+#endif
 __device__ __forceinline__ double sqrt_hot(double x) {
     const double xs = fmax(x, 1e-280);
     const double y = __builtin_amdgcn_rsq(xs);
@@ -80,8 +86,11 @@ __device__ __forceinline__ double sqrt_hot(double x) {
     double h = 0.5 * y;
     const double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
+#if CGLB_SQRT_STEPS >= 2
     const double d = __builtin_fma(-g, g, xs);  // residual ~ e0^2 xs: the first-order h (error e0) is accurate enough to apply it
-    return __builtin_fma(d, h, g);
+    g = __builtin_fma(d, h, g);
+#endif
+    return g;
 }
 __device__ __forceinline__ float sqrt_hot(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
 
@@ -103,7 +112,12 @@ __device__ __forceinline__ float tfma_(float a, float b, float c) { return __bui
 #endif
 #define CGLB_TAB_SIZE (1 << CGLB_TAB_BITS)
 #define CGLB_HOT_UNITS ((double)CGLB_TAB_SIZE)
-// P(s) = 2^(s / TAB_SIZE) on |s| <= 1/2 (max rel. error 1.1e-16 for each variant, fitted on Chebyshev nodes in extended precision)
+// P(s) = 2^(s / TAB_SIZE) on |s| <= 1/2, fitted on Chebyshev nodes in extended precision (tools/exp2_poly_fit.py).  The degree is a
+// build-time choice (CGLB_EXP_DEG); maximum relative error of the polynomial with TAB_BITS = 8: degree 4 4.8e-18 (1.1e-16 with
+// the Horner round-off), degree 3 3.5e-14, degree 2 2.1e-10.
+#ifndef CGLB_EXP_DEG
+#define CGLB_EXP_DEG ((CGLB_TAB_BITS == 6) ? 5 : 3)
+#endif
 template <typename T> __device__ __forceinline__ T exp2_tab_poly(T s) {
 #if CGLB_TAB_BITS == 6
     T p = T(0x1.5d8855325a3d0p-40);
@@ -111,19 +125,103 @@ template <typename T> __device__ __forceinline__ T exp2_tab_poly(T s) {
     p = tfma_(p, s, T(0x1.c6b08d7044d9dp-23));
     p = tfma_(p, s, T(0x1.ebfbdff829821p-15));
     p = tfma_(p, s, T(0x1.62e42fefa39efp-7));
-#elif CGLB_TAB_BITS == 8
+#elif CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 4
     T p = T(0x1.3b2ad0e3ae6d5p-39);
     p = tfma_(p, s, T(0x1.c6b090db83bfbp-29));
     p = tfma_(p, s, T(0x1.ebfbdff82beffp-19));
     p = tfma_(p, s, T(0x1.62e42fefa39b8p-9));
+#elif CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 3
+    T p = T(0x1.c6b08f7c960adp-29);
+    p = tfma_(p, s, T(0x1.ebfbe3a9ac80bp-19));
+    p = tfma_(p, s, T(0x1.62e42fefa39efp-9));
+#elif CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 2
+    T p = T(0x1.ebfbe26e81c82p-19);
+    p = tfma_(p, s, T(0x1.62e4337d04bc9p-9));
 #elif CGLB_TAB_BITS == 12
     T p = T(0x1.c6b0809952670p-41);
     p = tfma_(p, s, T(0x1.ebfbdffd0ae72p-27));
     p = tfma_(p, s, T(0x1.62e42fefa39f0p-13));
 #else
-#error "CGLB_TAB_BITS must be 6, 8 or 12"
+#error "unsupported CGLB_TAB_BITS / CGLB_EXP_DEG combination"
 #endif
     return tfma_(p, s, T(1));
+}
+// Floor form: P(s) = 2^((s - 1/2) / TAB_SIZE) on 0 <= s < 1 (the table then holds 2^((k + 1/2) / T)); free constant term.
+// TAB_BITS = 8: degree 4 1.7e-17, degree 3 1.8e-14, degree 2 1.0e-10.
+template <typename T> __device__ __forceinline__ T exp2_tab_poly_floor(T s) {
+#if CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 4
+    T p = T(0x1.3b2ab88f70400p-39);
+    p = tfma_(p, s, T(0x1.c612fb7dd6528p-29));
+    p = tfma_(p, s, T(0x1.eb517b4ddbd98p-19));
+    p = tfma_(p, s, T(0x1.6269464576054p-9));
+    return tfma_(p, s, T(0x1.ff4eaca4391b6p-1));
+#elif CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 3
+    T p = T(0x1.c6b0902b5a0abp-29);
+    p = tfma_(p, s, T(0x1.eb5162aec6f78p-19));
+    p = tfma_(p, s, T(0x1.62694646b129dp-9));
+    return tfma_(p, s, T(0x1.ff4eaca439118p-1));
+#elif CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 2
+    T p = T(0x1.ebfbe3a9ac80bp-19);
+    p = tfma_(p, s, T(0x1.6269364acae25p-9));
+    return tfma_(p, s, T(0x1.ff4eaca51c5ffp-1));
+#else
+    return exp2_tab_poly<T>(s - T(0.5));
+#endif
+}
+// Range reduction by floor/fract (CGLB_EXP_FLOOR): x = n + s with n = floor(x), s = v_fract_f64(x) (exact) - and n is obtained
+// WITHOUT a conversion: t = x + 1.5 * 2^52 added under round-toward-minus-infinity leaves floor(x) (two's complement) in the low
+// mantissa word of t.  The fp64 rounding mode (MODE.FP_ROUND[3:2]) is switched for exactly these adds inside one asm block, so no
+// other arithmetic sees it; n and s are consistent by construction (both floor-based, no tie cases).  2 issue slots (add, fract)
+// instead of 3 (rndne, sub, cvt).
+#ifndef CGLB_EXP_FLOOR
+#define CGLB_EXP_FLOOR (CGLB_TAB_BITS == 8)
+#endif
+#define CGLB_MAGIC_FLOOR 6755399441055744.0  // 1.5 * 2^52: low 32 mantissa bits zero, ulp 1
+template <bool NEG> __device__ __forceinline__ void floor_magic4(double x0, double x1, double x2, double x3, double& t0, double& t1, double& t2,
+                                                                 double& t3) {
+    const double magic = CGLB_MAGIC_FLOOR;
+    if (NEG)
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+                     "v_add_f64 %0, -%4, %8\n\tv_add_f64 %1, -%5, %8\n\tv_add_f64 %2, -%6, %8\n\tv_add_f64 %3, -%7, %8\n\t"
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                     : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(magic));
+    else
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+                     "v_add_f64 %0, %4, %8\n\tv_add_f64 %1, %5, %8\n\tv_add_f64 %2, %6, %8\n\tv_add_f64 %3, %7, %8\n\t"
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                     : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(magic));
+}
+template <bool NEG> __device__ __forceinline__ void floor_magic2(double x0, double x1, double& t0, double& t1) {
+    const double magic = CGLB_MAGIC_FLOOR;
+    if (NEG)
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+                     "v_add_f64 %0, -%2, %4\n\tv_add_f64 %1, -%3, %4\n\t"
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+                     : "=&v"(t0), "=&v"(t1)
+                     : "v"(x0), "v"(x1), "s"(magic));
+    else
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+                     "v_add_f64 %0, %2, %4\n\tv_add_f64 %1, %3, %4\n\t"
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+                     : "=&v"(t0), "=&v"(t1)
+                     : "v"(x0), "v"(x1), "s"(magic));
+}
+template <bool NEG> __device__ __forceinline__ void floor_magic1(double x0, double& t0) {
+    const double magic = CGLB_MAGIC_FLOOR;
+    if (NEG)
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+                     "v_add_f64 %0, -%1, %2\n\ts_nop 0\n\t"
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+                     : "=&v"(t0)
+                     : "v"(x0), "s"(magic));
+    else
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+                     "v_add_f64 %0, %1, %2\n\ts_nop 0\n\t"
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+                     : "=&v"(t0)
+                     : "v"(x0), "s"(magic));
 }
 // The table holds 2^(k/T) with (k << (20 - BITS)) subtracted from the high word, so that ONE integer instruction
 //   hi(entry[n & (T-1)]) + (n << (20 - BITS))  =  hi(2^(k/T)) + ((n >> BITS) << 20)
@@ -137,11 +235,52 @@ __device__ __forceinline__ double exp2_tab_scale(double entry, int ni) {
 }
 template <bool CLAMP> __device__ __forceinline__ double exp2_tab(double xh, const double* __restrict__ tab_lds) {
     if (CLAMP) xh = fmax(xh, -CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE);
+#if CGLB_EXP_FLOOR
+    double t;
+    floor_magic1<false>(xh, t);
+    const double s = __builtin_amdgcn_fract(xh);
+    const int ni = __double2loint(t);
+    return exp2_tab_scale(tab_lds[ni & (CGLB_TAB_SIZE - 1)], ni) * exp2_tab_poly_floor<double>(s);
+#else
     const double n = __builtin_rint(xh);
     const double s = xh - n;
     const int ni = (int)n;
     const double t = tab_lds[ni & (CGLB_TAB_SIZE - 1)];
     return exp2_tab_scale(t, ni) * exp2_tab_poly<double>(s);
+#endif
+}
+// R values at once: out[r] = 2^(x[r]/T) (NEG: 2^(-x[r]/T)); in the floor form the R round-down adds share one rounding-mode window
+template <bool CLAMP, bool NEG, int R>
+__device__ __forceinline__ void exp2_tab_batch(const double (&xin)[R], const double* __restrict__ tab_lds, double (&out)[R]) {
+#if CGLB_EXP_FLOOR
+    double x[R], t[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = CLAMP ? (NEG ? fmin(xin[r], CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE) : fmax(xin[r], -CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE)) : xin[r];
+    if constexpr (R % 4 == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r += 4) floor_magic4<NEG>(x[r], x[r + 1], x[r + 2], x[r + 3], t[r], t[r + 1], t[r + 2], t[r + 3]);
+    } else if constexpr (R % 2 == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) floor_magic2<NEG>(x[r], x[r + 1], t[r], t[r + 1]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) floor_magic1<NEG>(x[r], t[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double s = __builtin_amdgcn_fract(NEG ? -x[r] : x[r]);
+        const int ni = __double2loint(t[r]);
+        out[r] = exp2_tab_scale(tab_lds[ni & (CGLB_TAB_SIZE - 1)], ni) * exp2_tab_poly_floor<double>(s);
+    }
+#else
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r] = exp2_tab<CLAMP>(NEG ? -xin[r] : xin[r], tab_lds);
+#endif
+}
+template <bool CLAMP, bool NEG, int R>
+__device__ __forceinline__ void exp2_tab_batch(const float (&xin)[R], const double* __restrict__, float (&out)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r] = __builtin_amdgcn_exp2f((NEG ? -xin[r] : xin[r]) * (1.0f / (float)CGLB_TAB_SIZE));
 }
 template <bool CLAMP> __device__ __forceinline__ float exp2_tab(float xh, const double* __restrict__) {
     return __builtin_amdgcn_exp2f(xh * (1.0f / (float)CGLB_TAB_SIZE));
@@ -212,17 +351,73 @@ __device__ __forceinline__ KappaPend<T> kappa_hot_begin(T gram, T aj, const doub
     k.tabv = (T)tab[k.ni & (CGLB_TAB_SIZE - 1)];
     return k;
 }
-// polynomial part (independent of the table read): overwrites k.s with P5(s) [* lin for Matern]
+// Batched `begin` for the R rows a lane owns.  With CGLB_EXP_FLOOR (fp64) the range reduction is the floor/fract form and the R
+// round-down adds share one rounding-mode window (floor_magic*); the table passed in must then be the floor table (2^((k+1/2)/T)).
+template <typename T, int KIND, bool CLAMP, bool FOLDED, int R>
+__device__ __forceinline__ void kappa_hot_begin_batch(const T (&gram)[R], T aj, const double* __restrict__ tab, KappaPend<T> (&kp)[R]) {
+#if CGLB_EXP_FLOOR
+    if constexpr (sizeof(T) == 8) {
+        double x[R], t[R];  // RBF: x = exponent; Matern: x = r (the exponent is -r)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (KIND == CGLB_RBF) {
+                x[r] = FOLDED ? gram[r] : gram[r] + aj;
+                kp[r].lin = T(1);
+                if (CLAMP) x[r] = tmax<double>(x[r], -CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE);
+            } else {
+                const double d2 = tfma<double>(-2.0, gram[r], aj);
+                x[r] = sqrt_hot(d2);
+                kp[r].lin = tfma<double>(x[r], CGLB_LN2 / CGLB_HOT_UNITS, 1.0);
+                if (CLAMP) x[r] = tmin<double>(x[r], CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE);
+            }
+        }
+        constexpr bool NEG = KIND != CGLB_RBF;
+        if constexpr (R % 4 == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r += 4) floor_magic4<NEG>(x[r], x[r + 1], x[r + 2], x[r + 3], t[r], t[r + 1], t[r + 2], t[r + 3]);
+        } else if constexpr (R % 2 == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r += 2) floor_magic2<NEG>(x[r], x[r + 1], t[r], t[r + 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) floor_magic1<NEG>(x[r], t[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            kp[r].s = __builtin_amdgcn_fract(NEG ? -x[r] : x[r]);
+            kp[r].ni = __double2loint(t[r]);
+            kp[r].tabv = tab[kp[r].ni & (CGLB_TAB_SIZE - 1)];
+        }
+        return;
+    }
+#endif
+#pragma unroll
+    for (int r = 0; r < R; ++r) kp[r] = kappa_hot_begin<T, KIND, CLAMP, FOLDED>(gram[r], aj, tab);
+}
+// polynomial part (independent of the table read): overwrites k.s with P(s) [* lin for Matern]
 template <typename T, int KIND> __device__ __forceinline__ void kappa_hot_poly(KappaPend<T>& k) {
     T p;
     if (sizeof(T) == 4) p = (T)__builtin_amdgcn_exp2f((float)k.s * (1.0f / (float)CGLB_TAB_SIZE));
+#if CGLB_EXP_FLOOR
+    else p = exp2_tab_poly_floor<T>(k.s);
+#else
     else p = exp2_tab_poly<T>(k.s);
+#endif
     if (KIND != CGLB_RBF) p *= k.lin;
     k.s = p;
 }
 template <typename T, int KIND> __device__ __forceinline__ T kappa_hot_end(const KappaPend<T>& k) {
     if (sizeof(T) == 4) return k.s;
     return (T)(exp2_tab_scale((double)k.tabv, k.ni) * (double)k.s);
+}
+// one pair, same arithmetic as the batched form (ragged tails of the symmetric kernel)
+template <typename T, int KIND, bool CLAMP, bool FOLDED>
+__device__ __forceinline__ T kappa_hot_single(T gram, T aj, const double* __restrict__ tab) {
+    T g1[1] = {gram};
+    KappaPend<T> kp[1];
+    kappa_hot_begin_batch<T, KIND, CLAMP, FOLDED, 1>(g1, aj, tab, kp);
+    kappa_hot_poly<T, KIND>(kp[0]);
+    return kappa_hot_end<T, KIND>(kp[0]);
 }
 
 // gradient factor from an exact squared distance in hot units (RBF: d2h = 64 d2s; Matern32: d2h = 4096 d2s)

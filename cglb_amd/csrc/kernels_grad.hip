@@ -111,8 +111,10 @@ __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict_
         S0[k] = 0;
         const T a = ah[row0 + rr];
         aseed[k] = (KIND == CGLB_RBF) ? a : T(-0.5) * a;
-        ui[k] = row < n ? u[row0 + rr] : T(0);  // padded rows carry zero weight
-        vi[k] = row < n ? v[row0 + rr] : T(0);
+        // padded rows carry zero weight; Matern-3/2: h = 3 * 2^(-r), the factor 3 rides in the row weights
+        const T hscale = (KIND == CGLB_RBF) ? T(1) : T(3);
+        ui[k] = row < n ? hscale * u[row0 + rr] : T(0);
+        vi[k] = row < n ? hscale * v[row0 + rr] : T(0);
     }
     int64_t j0 = (int64_t)blockIdx.y * jchunk;
     const int64_t j1 = (j0 + jchunk < n) ? j0 + jchunk : n;
@@ -129,21 +131,20 @@ __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict_
             xj[d] = Xh[j * DP + d];
             sj[d] = Xhsq[j * DP + d];
         }
+        T earg[R], h[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             T g = aseed[k];
 #pragma unroll
             for (int d = 0; d < DP; ++d) g = tfma<T>(xi[k][d], xj[d], g);
-            T h;
-            if (KIND == CGLB_RBF) {
-                h = exp2_tab<false>(g + aj, tab);
-            } else {
-                const T d2 = tfma<T>(T(-2), g, aj);
-                h = T(3) * exp2_tab<false>(-sqrt_hot(d2), tab);
-            }
+            earg[k] = (KIND == CGLB_RBF) ? g + aj : sqrt_hot(tfma<T>(T(-2), g, aj));  // RBF: exponent; Matern: r (exponent -r)
+        }
+        exp2_tab_batch<false, KIND != CGLB_RBF, R>(earg, tab, h);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
             T w = ui[k] * vj;
             w = tfma<T>(vi[k], wu, w);
-            const T hv = h * w;
+            const T hv = h[k] * w;
             S0[k] += hv;
 #pragma unroll
             for (int d = 0; d < DP; ++d) {

@@ -8,7 +8,7 @@
 //   * the column operand (xs_j, a_j, p_j) is wave-uniform, so it is fetched with scalar loads into
 //     SGPRs and fed straight into v_fma_f64 as the scalar source: no VGPRs, no LDS traffic, no bank
 //     conflicts for the streamed side;
-//   * pair value by the Gram form (DP fma + 1 add), 2^x by rndne/add/11-fma/ldexp (devmath.h);
+//   * pair value by the Gram form (DP fma + 1 add), table-driven 2^x (devmath.h);
 //   * columns are split over blockIdx.y; partial row sums go to a [jsplit][nrows] slab and are
 //     combined in fixed order (bitwise reproducible, no atomics).
 #include "devmath.h"
@@ -35,20 +35,26 @@ __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ X
     }
     const int64_t j0 = col0 + (int64_t)blockIdx.y * jchunk;
     const int64_t j1 = (j0 + jchunk < col1) ? j0 + jchunk : col1;
-#pragma unroll 2
     for (int64_t j = j0; j < j1; ++j) {
         const T aj = xa[j];
         const T pj = p[j];
         T xj[DP];
 #pragma unroll
         for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
+        T gram[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            T gram = ai[k];
+            T g = ai[k];
 #pragma unroll
-            for (int d = 0; d < DP; ++d) gram = tfma<T>(xi[k][d], xj[d], gram);
-            const T kap = kappa_hot_from_gram<T, KIND, CLAMP>(gram, aj, tab);
-            acc[k] = tfma<T>(kap, pj, acc[k]);
+            for (int d = 0; d < DP; ++d) g = tfma<T>(xi[k][d], xj[d], g);
+            gram[k] = g;
+        }
+        KappaPend<T> kp[R];
+        kappa_hot_begin_batch<T, KIND, CLAMP, false, R>(gram, aj, tab, kp);  // the R range reductions share one rounding-mode window
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            kappa_hot_poly<T, KIND>(kp[k]);
+            acc[k] = tfma<T>(kappa_hot_end<T, KIND>(kp[k]), pj, acc[k]);
         }
     }
 #pragma unroll

@@ -136,8 +136,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(
                 }
             }
             KappaPend<T> kp[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) kp[r] = kappa_hot_begin<T, KIND, CLAMP, FOLD>(gram[r], aj, tab);
+            kappa_hot_begin_batch<T, KIND, CLAMP, FOLD, R>(gram, aj, tab, kp);
             __builtin_amdgcn_sched_barrier(0);  // all R table reads are in flight here ...
 #pragma unroll
             for (int r = 0; r < R; ++r) kappa_hot_poly<T, KIND>(kp[r]);
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(
             T gram = ai[r];
 #pragma unroll
             for (int d = 0; d < DP; ++d) gram = tfma<T>(PACKED ? (T)xi2[(r / 2) % RP][d][r % 2] : xi[r % RU][d], xj[d], gram);
-            const T kap = kappa_hot_from_gram<T, KIND, CLAMP>(gram, aj, tab);  // FOLD: aj == 0, the weight is in pj / applied below
+            const T kap = kappa_hot_single<T, KIND, CLAMP, FOLD>(gram, aj, tab);  // FOLD: the weight is in pj / applied below
             acc[r] = tfma<T>(kap, pj, acc[r]);
             tj = tfma<T>(kap, pr[r], tj);
         }
@@ -369,6 +368,18 @@ static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, i
                     if (src < T) items[b * WG + w] = sorted[src];
                 }
     }
+    // evaluated kernel pairs of one launch (cglb_get_stat "k1_pairs_per_launch"): rows of the block x columns at or right of its first row
+    double pairs = 0.0;
+    for (const int2& it : items) {
+        if (it.x < 0) continue;
+        const int64_t rbase = (int64_t)it.x * rbrows;
+        const int64_t rows = (n - rbase < rbrows) ? n - rbase : rbrows;
+        int64_t j0 = (int64_t)it.y * chunk, j1 = ((int64_t)it.y + 1) * chunk;
+        if (j0 < rbase) j0 = rbase;
+        if (j1 > n) j1 = n;
+        if (j1 > j0) pairs += (double)rows * (double)(j1 - j0);
+    }
+    c->sym_pairs = (rank < nrb) ? pairs : 0.0;
     if (c->sym_items) HIP_CHECK(c, hipFree(c->sym_items));
     c->sym_items = nullptr;
     if (items.empty()) items.push_back(make_int2(0, 0));  // keep the allocation non-empty; nitems stays 0

@@ -176,7 +176,9 @@ int cglb_get_matrix(cglb_ctx* ctx, int which, void* dst);
 int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
 /* In-situ measurement of the dominant kernel: after cglb_set_option(ctx, "k1_profile", 1) every launch of the symmetric pair
  * kernel (in mat-vecs, solves and evaluations alike) is bracketed by HIP events on the context stream; "k1_ms_total" and
- * "k1_launches" return the accumulated device time and launch count since then (the call synchronises with the pending launches). */
+ * "k1_launches" return the accumulated device time and launch count since then (the call synchronises with the pending launches).
+ * "k1_pairs_per_launch": kernel pairs one launch of that kernel evaluates with the current geometry (~N(N+256)/2 on one GPU: the
+ * symmetric form visits each unordered pair once) - the unit count of the roofline; "kpart_bytes": size of the partial-sum slabs. */
 int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
 /* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" | "sym_order" | "aat_block" | "grad_gram" | "k1_profile" ...;
  * returns CGLB_ERR_BAD_ARG if unknown. */

@@ -233,7 +233,7 @@ def kernel_grad_factor(kind, d2: np.ndarray, var) -> np.ndarray:
     return 3.0 * var * np.exp(-SQRT3 * np.sqrt(d2))
 
 
-def objective_grad(kind, X, hyp: Hypers, terms: CommonTerms, v: np.ndarray, w: np.ndarray) -> Dict[str, np.ndarray]:
+def objective_grad(kind, X, hyp: Hypers, terms: CommonTerms, v: np.ndarray, w: np.ndarray, blocked=None) -> Dict[str, np.ndarray]:
     """Gradient of ``bound`` wrt the constrained hypers with v held constant.
 
     This is what ``torch.autograd.grad(loss, variables)`` (pytorch/optimizer.py:95-98) yields
@@ -244,6 +244,9 @@ def objective_grad(kind, X, hyp: Hypers, terms: CommonTerms, v: np.ndarray, w: n
 
     with w = P r, c = Kuu^-1 Kuf w, tau = 1 + f/s - tr(AA^T)/N, s = noise, f = variance.
     Returns d bound / d{lengthscales, variance, noise, mean, Z}.
+
+    `blocked`: optional module with `grad_kff` / `kff_matvec` (oracle/cglb_oracle_c.py) — the two N^2 pieces are then
+    streamed instead of formed densely, so that the same formula runs at N = 100k.
     """
     N, D = X.shape
     M = hyp.Z.shape[0]
@@ -268,14 +271,19 @@ def objective_grad(kind, X, hyp: Hypers, terms: CommonTerms, v: np.ndarray, w: n
 
     Xs, Zs = X / ls, hyp.Z / ls
     # N^2 bilinear form (w + v/2)^T dKff v
-    d2 = scaled_sqdist(X, X, ls)
-    h = kernel_grad_factor(kind, d2, f)
-    k_ff = kernel_from_sqdist(kind, d2, f)
-    Wff = h * np.outer(u, v)
-    for d in range(D):
-        delta = Xs[:, d][:, None] - Xs[:, d][None, :]
-        g_ls[d] += float((Wff * delta * delta).sum()) / ls[d]
-    g_f = float(u @ (k_ff @ v)) / f
+    if blocked is not None:
+        g_ls += blocked.grad_kff(kind, X, hyp, u, v)
+        g_f = float(u @ (blocked.kff_matvec(kind, X, hyp, v) - s * v)) / f
+    else:
+        d2 = scaled_sqdist(X, X, ls)
+        h = kernel_grad_factor(kind, d2, f)
+        k_ff = kernel_from_sqdist(kind, d2, f)
+        Wff = h * np.outer(u, v)
+        for d in range(D):
+            delta = Xs[:, d][:, None] - Xs[:, d][None, :]
+            g_ls[d] += float((Wff * delta * delta).sum()) / ls[d]
+        g_f = float(u @ (k_ff @ v)) / f
+        del d2, h, k_ff, Wff
     # Kuf part
     d2 = scaled_sqdist(hyp.Z, X, ls)
     h = kernel_grad_factor(kind, d2, f)

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Headline-size fixtures (N = 100 000, D = 8, M = 1024, fp64) from the REFERENCE's own solver.  TEST INFRASTRUCTURE ONLY.
+
+Runs only in the build container (needs /root/reference, ~10-20 CPU-minutes per case on 8 cores); the produced
+`tests/golden/headline/*.npz` are committed, this script is the record of how they were made.
+
+What comes from the reference: `ConjugateGradient.__call__` and `NystromPreconditioner.__call__`
+(cglb/backend/pytorch/conjugate_gradient.py:41-113, loaded by file path exactly like oracle/gen_golden.py) drive the
+solve.  The operator handed to them is an object whose `@` is the blocked C restatement of
+`kernel(x).add_diag(sigma^2) @ p` (oracle/cglb_oracle.c: direct differences, libm exp/sqrt, K_ff never formed) — the
+reference only ever uses `A @ x` (conjugate_gradient.py:57,66,72).
+What is restated: common terms (models.py:176-213), log-det (:215-244), bound assembly (:280-286) in numpy
+(oracle/cglb_oracle.py, oracle/cglb_oracle_c.py), and the analytic gradient with the N^2 pieces from the blocked C oracle.
+
+Stored per case: steps, 1/2 r^T P r, bound, lower, upper, logdet, the gradient wrt the constrained hypers, a strided
+sample of v, and the inputs' recipe (seed, sizes, hypers) — X, y, Z are regenerated from the seed by the tests.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import cglb_oracle as orc  # noqa: E402
+from oracle import cglb_oracle_c as orcc  # noqa: E402
+from oracle.gen_golden import load_reference_cg  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "headline")  # own directory: conftest.golden_names() globs tests/golden/*.npz
+V_STRIDE = 97
+
+
+class BlockedOperator:
+    """`K_ff + sigma^2 I` as an object with `@` only (the operator seam, conjugate_gradient.py:43)."""
+
+    def __init__(self, kind, X, hyp):
+        self.kind, self.X, self.hyp, self.calls = kind, X, hyp, 0
+
+    def __matmul__(self, x: torch.Tensor) -> torch.Tensor:
+        self.calls += 1
+        out = orcc.kff_matvec(self.kind, self.X, self.hyp, x.detach().numpy().reshape(-1))
+        return torch.from_numpy(out).reshape(x.shape)
+
+
+def make_case(ref, name, kind, N, D, M, seed, hyp_kind, max_error=1.0, max_cg_iter=100, restart=40):
+    t0 = time.time()
+    X, y, Z = orc.synthetic_problem(N, D, M, seed)
+    hyp = orc.reference_init_hypers(D, Z) if hyp_kind == "init" else orc.trained_like_hypers(D, Z)
+    terms = orcc.common_terms(kind, X, hyp)
+    logdet = orc.logdet_estimator(kind, X, hyp, terms)
+    const = -0.5 * N * np.log(2.0 * np.pi)
+    op = BlockedOperator(kind, X, hyp)
+    err = torch.from_numpy(y.reshape(-1, 1) - hyp.mean)
+    tA, tLB = torch.from_numpy(terms.A), torch.from_numpy(terms.LB)
+    precon = ref.NystromPreconditioner(tA, tLB, torch.tensor(hyp.noise, dtype=torch.float64))
+    cg_opt = ref.ConjugateGradient(max_error=max_error, max_cg_iter=max_cg_iter, restart_cg_iter=restart)
+    with torch.no_grad():
+        v, stats = cg_opt(op, err, torch.zeros((N, 1), dtype=torch.float64), precon)      # models.py:266-271
+        cov_v = op @ v                                                                    # :280
+        r = err - cov_v                                                                   # :281
+        w, error_bound = precon(r)                                                        # :282
+        lower = float((v * (r + 0.5 * cov_v)).sum())                                      # :283
+        upper = lower + 0.5 * float(error_bound)                                          # :284
+    bound = -upper + logdet + const                                                       # :286, :169
+    vn, wn = v.numpy().reshape(-1), w.numpy().reshape(-1)
+    grad = orc.objective_grad(kind, X, hyp, terms, vn, wn, blocked=orcc)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        kind=np.int64(orc.kind_id(kind)), N=np.int64(N), D=np.int64(D), M=np.int64(M), seed=np.int64(seed),
+        hyp_kind=np.array(hyp_kind), lengthscales=hyp.lengthscales, variance=np.float64(hyp.variance),
+        noise=np.float64(hyp.noise), mean=np.float64(hyp.mean), jitter=np.float64(hyp.jitter),
+        max_error=np.float64(max_error), max_cg_iter=np.int64(max_cg_iter), restart_cg_iter=np.int64(restart),
+        steps=np.int64(int(stats.steps)), residual_error=np.float64(float(stats.residual_error)),
+        bound=np.float64(bound), lower=np.float64(lower), upper=np.float64(upper), logdet=np.float64(logdet),
+        AAt_diag_sum=np.float64(terms.AAt_diag_sum), matvecs=np.int64(op.calls),
+        v_stride=np.int64(V_STRIDE), v_sample=vn[::V_STRIDE].copy(), v_norm=np.float64(np.linalg.norm(vn)),
+        g_lengthscales=grad["lengthscales"], g_variance=np.float64(grad["variance"]), g_noise=np.float64(grad["noise"]),
+        g_mean=np.float64(grad["mean"]), g_Z=grad["Z"],
+    )
+    print(f"{name}: N={N} D={D} M={M} steps={int(stats.steps)} half_rz={float(stats.residual_error):.6e} "
+          f"bound={bound:.9f} lower={lower:.9f} upper={upper:.9f} matvecs={op.calls} ({time.time() - t0:.0f} s)", flush=True)
+
+
+CASES = {
+    # name: kind, N, D, M, seed, hypers
+    "headline_rbf_init": ("rbf", 100_000, 8, 1024, 0, "init"),
+    "headline_rbf_trained": ("rbf", 100_000, 8, 1024, 0, "trained"),        # bench.py's default workload
+    "headline_m32_trained": ("matern32", 100_000, 8, 1024, 0, "trained"),
+    "c2_rbf_trained": ("rbf", 50_000, 8, 1024, 0, "trained"),               # BASELINE config C2
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cases", nargs="*", default=list(CASES))
+    ap.add_argument("--threads", type=int, default=0)
+    args = ap.parse_args()
+    if args.threads:
+        orcc.set_num_threads(args.threads)
+        torch.set_num_threads(args.threads)
+    ref = load_reference_cg()
+    torch.set_default_dtype(torch.float64)
+    for name in args.cases:
+        make_case(ref, name, *CASES[name])
+
+
+if __name__ == "__main__":
+    main()

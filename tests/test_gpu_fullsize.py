@@ -12,7 +12,8 @@ from oracle import cglb_oracle_c as orcc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[(50_000, "rbf"), (100_000, "matern32")])
+@pytest.fixture(scope="module", params=[(50_000, "rbf"), (100_000, "rbf"), (100_000, "matern32")],
+                ids=["c2_50k_rbf", "headline_100k_rbf", "headline_100k_matern32"])
 def big(request):
     from cglb_amd.hip_context import HipContext
     N, kind = request.param
