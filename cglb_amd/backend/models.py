@@ -228,6 +228,7 @@ class _BoundFunction(torch.autograd.Function):
         if run_cg:
             owner.cached_v_vec = owner._use_cache                       # models.py:278
         owner.last_bounds = Bounds(upper_bound=torch.tensor(-res.upper), lower_bound=torch.tensor(-res.lower))  # models.py:286
+        model.last_bound = float(res.bound)  # value of the most recent evaluation (diagnostics / tests)
         ctx.grads = res.grad
         return torch.tensor(res.bound, dtype=torch.float64)
 

@@ -471,10 +471,10 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     CR(dalloc(c, &c->Zh, M * Dp * e)); CR(dalloc(c, &c->zah, M * e)); CR(dalloc(c, &c->Linv, M * M * e)); CR(dalloc(c, &c->LinvT, M * M * e));
     CR(dalloc(c, &c->w_q, M * e));
     CR(dalloc(c, &c->Xh, N * Dp * e)); CR(dalloc(c, &c->Xhsq, N * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, &c->wh, N * e)); CR(dalloc(c, &c->pwh, N * e)); CR(dalloc(c, (void**)&c->exp_tab, CGLB_TAB_SIZE * sizeof(double)));
-    {   // 2^x table of the pair kernels: centred form 2^(k/T), or 2^((k + 1/2)/T) for the floor/fract range reduction (devmath.h)
+    {   // 2^x table of the pair kernels: 2^((k + 1/2)/T) for the floor/fract range reduction (devmath.h)
         std::vector<double> tab(CGLB_TAB_SIZE);
         for (int k = 0; k < CGLB_TAB_SIZE; ++k) {
-            const double v = std::exp2(((double)k + (CGLB_EXP_FLOOR ? 0.5 : 0.0)) / (double)CGLB_TAB_SIZE);  // glibc exp2: < 1 ulp
+            const double v = std::exp2(((double)k + 0.5) / (double)CGLB_TAB_SIZE);  // glibc exp2: < 1 ulp
             uint64_t bits;
             std::memcpy(&bits, &v, 8);
             bits -= (uint64_t)k << (52 - CGLB_TAB_BITS);  // pre-compensated for the one-add scaling (devmath.h exp2_tab_scale)
@@ -535,6 +535,10 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
         if (value) { c->k1_events_used = 0; c->k1_ms_total = 0.0; c->k1_launches = 0; }
         else CGLB_TRY(k1_profile_collect(c));
         c->k1_profile = value != 0;
+    }
+    else if (!strcmp(name, "precision")) {
+        if (value != CGLB_PREC_EXACT && value != CGLB_PREC_FAST) return cglb_fail(c, CGLB_ERR_BAD_ARG, "precision must be 0 (exact) or 1 (fast)");
+        c->precision = (int)value;
     }
     else if (!strcmp(name, "chol_mode")) c->chol_mode = (int)value;
     else if (!strcmp(name, "precond_mode")) { c->precond_mode = (int)value; c->have_local = c->have_terms = false; }

@@ -91,6 +91,7 @@ struct cglb_ctx {
     size_t gpart_cap = 0;
     double* gradbuf = nullptr;     // device packed gradient [GRAD_LEN]
     // tunables
+    int precision = 1;  // CGLB_PREC_FAST (devmath.h): kernel values to <= 1e-13; 0 = CGLB_PREC_EXACT (~3e-16)
     int kff_variant = 2, kff_jsplit = 0, kff_rows = 4;  // 0 plain, 1 matrix-pipe Gram (fp64), 2 symmetric (default)
     bool exp_clamp = false;         // scaled operands so large that 2^x needs the range clamp (set by set_hypers)
     bool kff_skip_combine = false;  // timing only: launch the pair kernel without the slab combine

@@ -71,111 +71,69 @@ __device__ __forceinline__ double sqrt_pos(double x) {
 }
 __device__ __forceinline__ float sqrt_pos(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
 
-// Hot-loop variant for a squared distance that may come out slightly negative (Gram form): the clamp to a tiny positive
+// ---- precision levels of the pair kernels (cglb_set_option "precision") ------------------------------------------------------
+//   CGLB_PREC_EXACT (0): degree-4 table polynomial + two-step square root: kernel values to ~3e-16 (1.5 ulp)
+//   CGLB_PREC_FAST  (1): degree-3 polynomial (3.5e-14) + one-step square root (2.1e-14 on r): kernel values to <= ~1e-13 relative.
+// north_star asks for 1e-6 on the bound; FAST is the default (one fma per pair less, two for Matern-3/2).  Every fp64 instruction
+// of the pair stream is ~5 % of the mat-vec (the kernels are bound by vector-fp64 issue).
+#define CGLB_PREC_EXACT 0
+#define CGLB_PREC_FAST 1
+
+// Hot-loop square root for a squared distance that may come out slightly negative (Gram form): the clamp to a tiny positive
 // number replaces both the max(.,0) and the x > 0 select; sqrt_hot(d2 <= 0) = 1e-140, which the Matern profile maps to 1.
-// CGLB_SQRT_STEPS == 2: Goldschmidt step + residual correction (error ~ e0^3, below the rounding of the last fma; 8 + 4 issue slots).
-// CGLB_SQRT_STEPS == 1: the Goldschmidt step alone: relative error <= 1.5 e0^2 = 2.1e-14 with the 2^-23 seed of v_rsq_f64
-//                       (6 + 4 issue slots) - the "fast" precision level, see DESIGN.md section 4.
-#ifndef CGLB_SQRT_STEPS
-#define CGLB_SQRT_STEPS 1
-#endif
-__device__ __forceinline__ double sqrt_hot(double x) {
+// v_rsq_f64 seed (relative error e0 <= 2^-23, 4 issue slots), one Goldschmidt step (error 1.5 e0^2 = 2.1e-14; 5 more slots with the
+// clamp), and at CGLB_PREC_EXACT a residual correction with the first-order h (error ~ e0^3, below the rounding of the last fma).
+template <int PREC> __device__ __forceinline__ double sqrt_hot(double x) {
     const double xs = fmax(x, 1e-280);
     const double y = __builtin_amdgcn_rsq(xs);
     double g = xs * y;
     double h = 0.5 * y;
     const double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
-#if CGLB_SQRT_STEPS >= 2
-    const double d = __builtin_fma(-g, g, xs);  // residual ~ e0^2 xs: the first-order h (error e0) is accurate enough to apply it
-    g = __builtin_fma(d, h, g);
-#endif
+    if (PREC == CGLB_PREC_EXACT) {
+        const double d = __builtin_fma(-g, g, xs);  // residual ~ e0^2 xs: the first-order h (error e0) is accurate enough to apply it
+        g = __builtin_fma(d, h, g);
+    }
     return g;
 }
-__device__ __forceinline__ float sqrt_hot(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
+template <int PREC> __device__ __forceinline__ float sqrt_hot(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
 
 __device__ __forceinline__ double tfma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float tfma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// Table-driven 2^(xh/T), T = 2^CGLB_TAB_BITS: the hot pair kernels keep their operands in units of 1/T octave (xh = T*log2 of the
-// value), so  xh = n + s, |s| <= 1/2;  2^(xh/T) = 2^(n >> BITS) * TAB[n & (T-1)] * P(s),  TAB[k] = 2^(k/T) (correctly rounded, in LDS),
-//   P = polynomial for 2^(s/T) (1.1e-16).  Total error <= ~3e-16 (1.5 ulp).
-// fp64 has no hardware transcendental on CDNA and the pair kernels are bound by vector-fp64 issue, so every instruction here is
-// ~4 % of the mat-vec: with T = 256 this is 9 vector-fp64 instructions (rndne, add, 4 fma, cvt, mul, ldexp) + 3 cheap 32-bit
-// integer ops + one ds_read_b64, against 14 for the pure polynomial form.
-// Table size is a build-time choice: 6 -> 64 entries (512 B) + degree 5, 8 -> 256 entries (2 KB) + degree 4 (default),
-// 12 -> 4096 entries (32 KB) + degree 3.  Each step trades one fma per pair for LDS footprint and bank conflicts; measured
-// mat-vec at N = 100k, D = 8 (MI355X): 3.69 / 3.47 / 3.45 ms - beyond 256 entries the random-index ds_read_b64 (one per pair,
-// four SIMDs sharing the CU's LDS port) eats the fma that the shorter polynomial saves.
-#ifndef CGLB_TAB_BITS
+// Table-driven 2^(xh/T), T = 256: the hot pair kernels keep their operands in units of 1/T octave (xh = T * log2 of the value):
+//   xh = n + s, n = floor(xh), 0 <= s < 1;   2^(xh/T) = 2^(n >> 8) * TAB[n & 255] * P(s),
+//   TAB[k] = 2^((k + 1/2)/T) (correctly rounded, in LDS), P(s) = 2^((s - 1/2)/T) a polynomial (tools/exp2_poly_fit.py).
+// fp64 has no hardware transcendental on CDNA.  Instruction count of one 2^x (every one a 4-cycle issue slot of the SIMD):
+//   range reduction 2 (round-down add of 1.5 * 2^52, v_fract_f64)  [was 3: rndne, sub, cvt]
+//   table address 1 (SDWA byte extract + shift), ds_read_b64 (LDS pipe, not VALU)
+//   polynomial 3 fma at CGLB_PREC_FAST / 4 at CGLB_PREC_EXACT
+//   octave scaling 1 (v_lshl_add_u32 into the exponent field), product 1          -> 8 (FAST) / 9 (EXACT), against 14 for a
+//   pure polynomial 2^x.  Table size history (round 1, N = 100k D = 8): 64 entries + degree 5 3.69 ms, 256 + degree 4 3.47 ms,
+//   4096 + degree 3 3.45 ms (the byte-select addressing only exists for 8 bits: a 12-bit index costs the instruction the shorter
+//   polynomial saves).
 #define CGLB_TAB_BITS 8
-#endif
 #define CGLB_TAB_SIZE (1 << CGLB_TAB_BITS)
 #define CGLB_HOT_UNITS ((double)CGLB_TAB_SIZE)
-// P(s) = 2^(s / TAB_SIZE) on |s| <= 1/2, fitted on Chebyshev nodes in extended precision (tools/exp2_poly_fit.py).  The degree is a
-// build-time choice (CGLB_EXP_DEG); maximum relative error of the polynomial with TAB_BITS = 8: degree 4 4.8e-18 (1.1e-16 with
-// the Horner round-off), degree 3 3.5e-14, degree 2 2.1e-10.
-#ifndef CGLB_EXP_DEG
-#define CGLB_EXP_DEG ((CGLB_TAB_BITS == 6) ? 5 : 3)
-#endif
-template <typename T> __device__ __forceinline__ T exp2_tab_poly(T s) {
-#if CGLB_TAB_BITS == 6
-    T p = T(0x1.5d8855325a3d0p-40);
-    p = tfma_(p, s, T(0x1.3b2ad54ddd7adp-31));
-    p = tfma_(p, s, T(0x1.c6b08d7044d9dp-23));
-    p = tfma_(p, s, T(0x1.ebfbdff829821p-15));
-    p = tfma_(p, s, T(0x1.62e42fefa39efp-7));
-#elif CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 4
-    T p = T(0x1.3b2ad0e3ae6d5p-39);
-    p = tfma_(p, s, T(0x1.c6b090db83bfbp-29));
-    p = tfma_(p, s, T(0x1.ebfbdff82beffp-19));
-    p = tfma_(p, s, T(0x1.62e42fefa39b8p-9));
-#elif CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 3
-    T p = T(0x1.c6b08f7c960adp-29);
-    p = tfma_(p, s, T(0x1.ebfbe3a9ac80bp-19));
-    p = tfma_(p, s, T(0x1.62e42fefa39efp-9));
-#elif CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 2
-    T p = T(0x1.ebfbe26e81c82p-19);
-    p = tfma_(p, s, T(0x1.62e4337d04bc9p-9));
-#elif CGLB_TAB_BITS == 12
-    T p = T(0x1.c6b0809952670p-41);
-    p = tfma_(p, s, T(0x1.ebfbdffd0ae72p-27));
-    p = tfma_(p, s, T(0x1.62e42fefa39f0p-13));
-#else
-#error "unsupported CGLB_TAB_BITS / CGLB_EXP_DEG combination"
-#endif
-    return tfma_(p, s, T(1));
+// P(s) = 2^((s - 1/2) / 256) on 0 <= s < 1; maximum relative error: degree 4 1.7e-17 (+ Horner round-off ~1e-16), degree 3 1.8e-14
+template <int PREC> __device__ __forceinline__ double exp2_tab_poly(double s) {
+    if (PREC == CGLB_PREC_EXACT) {
+        double p = 0x1.3b2ab88f70400p-39;
+        p = __builtin_fma(p, s, 0x1.c612fb7dd6528p-29);
+        p = __builtin_fma(p, s, 0x1.eb517b4ddbd98p-19);
+        p = __builtin_fma(p, s, 0x1.6269464576054p-9);
+        return __builtin_fma(p, s, 0x1.ff4eaca4391b6p-1);
+    }
+    double p = 0x1.c6b0902b5a0abp-29;
+    p = __builtin_fma(p, s, 0x1.eb5162aec6f78p-19);
+    p = __builtin_fma(p, s, 0x1.62694646b129dp-9);
+    return __builtin_fma(p, s, 0x1.ff4eaca439118p-1);
 }
-// Floor form: P(s) = 2^((s - 1/2) / TAB_SIZE) on 0 <= s < 1 (the table then holds 2^((k + 1/2) / T)); free constant term.
-// TAB_BITS = 8: degree 4 1.7e-17, degree 3 1.8e-14, degree 2 1.0e-10.
-template <typename T> __device__ __forceinline__ T exp2_tab_poly_floor(T s) {
-#if CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 4
-    T p = T(0x1.3b2ab88f70400p-39);
-    p = tfma_(p, s, T(0x1.c612fb7dd6528p-29));
-    p = tfma_(p, s, T(0x1.eb517b4ddbd98p-19));
-    p = tfma_(p, s, T(0x1.6269464576054p-9));
-    return tfma_(p, s, T(0x1.ff4eaca4391b6p-1));
-#elif CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 3
-    T p = T(0x1.c6b0902b5a0abp-29);
-    p = tfma_(p, s, T(0x1.eb5162aec6f78p-19));
-    p = tfma_(p, s, T(0x1.62694646b129dp-9));
-    return tfma_(p, s, T(0x1.ff4eaca439118p-1));
-#elif CGLB_TAB_BITS == 8 && CGLB_EXP_DEG == 2
-    T p = T(0x1.ebfbe3a9ac80bp-19);
-    p = tfma_(p, s, T(0x1.6269364acae25p-9));
-    return tfma_(p, s, T(0x1.ff4eaca51c5ffp-1));
-#else
-    return exp2_tab_poly<T>(s - T(0.5));
-#endif
-}
-// Range reduction by floor/fract (CGLB_EXP_FLOOR): x = n + s with n = floor(x), s = v_fract_f64(x) (exact) - and n is obtained
-// WITHOUT a conversion: t = x + 1.5 * 2^52 added under round-toward-minus-infinity leaves floor(x) (two's complement) in the low
-// mantissa word of t.  The fp64 rounding mode (MODE.FP_ROUND[3:2]) is switched for exactly these adds inside one asm block, so no
-// other arithmetic sees it; n and s are consistent by construction (both floor-based, no tie cases).  2 issue slots (add, fract)
-// instead of 3 (rndne, sub, cvt).
-#ifndef CGLB_EXP_FLOOR
-#define CGLB_EXP_FLOOR (CGLB_TAB_BITS == 8)
-#endif
+// Range reduction by floor/fract: n = floor(x) is obtained WITHOUT a conversion: t = x + 1.5 * 2^52 added under
+// round-toward-minus-infinity leaves floor(x) (two's complement) in the low mantissa word of t; s = v_fract_f64(x) is exact, and
+// n and s are consistent by construction (both floor-based, no tie cases).  The fp64 rounding mode (MODE.FP_ROUND[3:2]) is switched
+// for exactly these adds inside one asm block, so no other arithmetic sees it (the mode is per wave).  A lane's R values share
+// one window: 2 SALU instructions per R adds.
 #define CGLB_MAGIC_FLOOR 6755399441055744.0  // 1.5 * 2^52: low 32 mantissa bits zero, ulp 1
 template <bool NEG> __device__ __forceinline__ void floor_magic4(double x0, double x1, double x2, double x3, double& t0, double& t1, double& t2,
                                                                  double& t3) {
@@ -223,39 +181,8 @@ template <bool NEG> __device__ __forceinline__ void floor_magic1(double x0, doub
                      : "=&v"(t0)
                      : "v"(x0), "s"(magic));
 }
-// The table holds 2^(k/T) with (k << (20 - BITS)) subtracted from the high word, so that ONE integer instruction
-//   hi(entry[n & (T-1)]) + (n << (20 - BITS))  =  hi(2^(k/T)) + ((n >> BITS) << 20)
-// puts the octave count straight into the exponent field (v_lshl_add_u32 instead of v_ashrrev + v_ldexp_f64).  Unlike ldexp
-// this cannot underflow gracefully: callers keep n / T inside [-1000, 1000] (range check in set_hypers or the CLAMP variant,
-// which then returns 2^-1000 ~ 1e-301 where ldexp would have returned 0).
-#define CGLB_EXP_FLOOR_OCT 1000.0
-__device__ __forceinline__ double exp2_tab_scale(double entry, int ni) {
-    const int hi = __double2hiint(entry) + (int)((unsigned)ni << (20 - CGLB_TAB_BITS));
-    return __hiloint2double(hi, __double2loint(entry));
-}
-template <bool CLAMP> __device__ __forceinline__ double exp2_tab(double xh, const double* __restrict__ tab_lds) {
-    if (CLAMP) xh = fmax(xh, -CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE);
-#if CGLB_EXP_FLOOR
-    double t;
-    floor_magic1<false>(xh, t);
-    const double s = __builtin_amdgcn_fract(xh);
-    const int ni = __double2loint(t);
-    return exp2_tab_scale(tab_lds[ni & (CGLB_TAB_SIZE - 1)], ni) * exp2_tab_poly_floor<double>(s);
-#else
-    const double n = __builtin_rint(xh);
-    const double s = xh - n;
-    const int ni = (int)n;
-    const double t = tab_lds[ni & (CGLB_TAB_SIZE - 1)];
-    return exp2_tab_scale(t, ni) * exp2_tab_poly<double>(s);
-#endif
-}
-// R values at once: out[r] = 2^(x[r]/T) (NEG: 2^(-x[r]/T)); in the floor form the R round-down adds share one rounding-mode window
-template <bool CLAMP, bool NEG, int R>
-__device__ __forceinline__ void exp2_tab_batch(const double (&xin)[R], const double* __restrict__ tab_lds, double (&out)[R]) {
-#if CGLB_EXP_FLOOR
-    double x[R], t[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = CLAMP ? (NEG ? fmin(xin[r], CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE) : fmax(xin[r], -CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE)) : xin[r];
+// floor of R values (NEG: of their negatives) into the low word of t[r]
+template <bool NEG, int R> __device__ __forceinline__ void floor_magic(const double (&x)[R], double (&t)[R]) {
     if constexpr (R % 4 == 0) {
 #pragma unroll
         for (int r = 0; r < R; r += 4) floor_magic4<NEG>(x[r], x[r + 1], x[r + 2], x[r + 3], t[r], t[r + 1], t[r + 2], t[r + 3]);
@@ -266,23 +193,44 @@ __device__ __forceinline__ void exp2_tab_batch(const double (&xin)[R], const dou
 #pragma unroll
         for (int r = 0; r < R; ++r) floor_magic1<NEG>(x[r], t[r]);
     }
+}
+// The table holds 2^((k + 1/2)/T) with (k << (20 - BITS)) subtracted from the high word, so that ONE integer instruction
+//   hi(entry[n & (T-1)]) + (n << (20 - BITS))  =  hi(2^((k + 1/2)/T)) + ((n >> BITS) << 20)
+// puts the octave count straight into the exponent field (v_lshl_add_u32 instead of v_ashrrev + v_ldexp_f64).  Unlike ldexp
+// this cannot underflow gracefully: callers keep n / T inside [-1000, 1000] (range check in set_hypers or the CLAMP variant,
+// which then returns 2^-1000 ~ 1e-301 where ldexp would have returned 0).
+#define CGLB_EXP_FLOOR_OCT 1000.0
+__device__ __forceinline__ double exp2_tab_scale(double entry, int ni) {
+    const int hi = __double2hiint(entry) + (int)((unsigned)ni << (20 - CGLB_TAB_BITS));
+    return __hiloint2double(hi, __double2loint(entry));
+}
+// R values at once: out[r] = 2^(x[r]/T) (NEG: 2^(-x[r]/T))
+template <bool CLAMP, bool NEG, int PREC, int R>
+__device__ __forceinline__ void exp2_tab_batch(const double (&xin)[R], const double* __restrict__ tab_lds, double (&out)[R]) {
+    double x[R], t[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        x[r] = CLAMP ? (NEG ? fmin(xin[r], CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE) : fmax(xin[r], -CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE)) : xin[r];
+    floor_magic<NEG, R>(x, t);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const double s = __builtin_amdgcn_fract(NEG ? -x[r] : x[r]);
         const int ni = __double2loint(t[r]);
-        out[r] = exp2_tab_scale(tab_lds[ni & (CGLB_TAB_SIZE - 1)], ni) * exp2_tab_poly_floor<double>(s);
+        out[r] = exp2_tab_scale(tab_lds[ni & (CGLB_TAB_SIZE - 1)], ni) * exp2_tab_poly<PREC>(s);
     }
-#else
-#pragma unroll
-    for (int r = 0; r < R; ++r) out[r] = exp2_tab<CLAMP>(NEG ? -xin[r] : xin[r], tab_lds);
-#endif
 }
-template <bool CLAMP, bool NEG, int R>
+template <bool CLAMP, bool NEG, int PREC, int R>
 __device__ __forceinline__ void exp2_tab_batch(const float (&xin)[R], const double* __restrict__, float (&out)[R]) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) out[r] = __builtin_amdgcn_exp2f((NEG ? -xin[r] : xin[r]) * (1.0f / (float)CGLB_TAB_SIZE));
+    for (int r = 0; r < R; ++r) out[r] = __builtin_amdgcn_exp2f((NEG ? -xin[r] : xin[r]) * (1.0f / (float)CGLB_TAB_SIZE));  // hardware exp2
 }
-template <bool CLAMP> __device__ __forceinline__ float exp2_tab(float xh, const double* __restrict__) {
+template <bool CLAMP, int PREC> __device__ __forceinline__ double exp2_tab(double xh, const double* __restrict__ tab_lds) {
+    const double x1[1] = {xh};
+    double o1[1];
+    exp2_tab_batch<CLAMP, false, PREC, 1>(x1, tab_lds, o1);
+    return o1[0];
+}
+template <bool CLAMP, int PREC> __device__ __forceinline__ float exp2_tab(float xh, const double* __restrict__) {
     return __builtin_amdgcn_exp2f(xh * (1.0f / (float)CGLB_TAB_SIZE));
 }
 
@@ -296,7 +244,6 @@ template <typename T> __device__ __forceinline__ T tmin(T a, T b) { return a < b
 //   RBF:      xs = (x-c)/l*sqrt(log2 e), a = -|xs|^2/2      kappa = 2^(a_i + a_j + xs_i.xs_j)
 //   Matern32: xs = (x-c)/l*sqrt3*log2 e, a = |xs|^2          r' = sqrt(max(a_i+a_j-2 xs_i.xs_j,0)),
 //             kappa = (1 + r' ln2) 2^(-r')
-// `g` receives the gradient factor h/var (RBF: kappa; Matern32: 3*2^(-r')), see kernels_grad.hip.
 // `gram` = a_i + xs_i.xs_j (the fma chain is seeded with a_i).  RBF: arg = gram + a_j may come out a few ulp
 // above 0 for coincident points; 2^arg is then 1 + O(1e-16), harmless, so no clamp is spent on it.
 template <typename T, int KIND, bool CLAMP> __device__ __forceinline__ T kappa_from_gram(T gram, T aj) {
@@ -310,52 +257,15 @@ template <typename T, int KIND, bool CLAMP> __device__ __forceinline__ T kappa_f
     }
 }
 
-// Hot-unit forms (operands scaled so that exponents are in 1/T octave, see exp2_tab):
-//   RBF:      xh = 8 xs, ah = 64 a          kappa = 2^((ah_i + ah_j + xh_i.xh_j)/64)
-//   Matern32: xh = 64 xs, ah = 4096 a       r64 = sqrt(max(ah_i + ah_j - 2 xh_i.xh_j, 0)),  kappa = (1 + r64 ln2/64) 2^(-r64/64)
-template <typename T, int KIND, bool CLAMP>
-__device__ __forceinline__ T kappa_hot_from_gram(T gram, T aj, const double* __restrict__ tab) {
-    if (KIND == CGLB_RBF) {
-        return exp2_tab<CLAMP>(gram + aj, tab);
-    } else {
-        T d2 = tfma<T>(T(-2), gram, aj);
-        T r = sqrt_hot(d2);
-        return tfma<T>(r, T(CGLB_LN2 / CGLB_HOT_UNITS), T(1)) * exp2_tab<CLAMP>(-r, tab);
-    }
-}
-// Two-phase form of kappa_hot_from_gram for software-pipelined loops: `begin` does the range reduction and issues the
-// table read, `end` consumes it, so that a loop can start the R lookups of a column before any of them is needed.
+// Hot-unit forms (operands scaled so that exponents are in 1/T octave, see exp2_tab_batch):
+//   RBF:      xh = 16 xs, ah = 256 a          kappa = 2^((ah_i + ah_j + xh_i.xh_j)/256)
+//   Matern32: xh = 256 xs, ah = 65536 a       rT = sqrt(max(ah_i + ah_j - 2 xh_i.xh_j, 0)),  kappa = (1 + rT ln2/256) 2^(-rT/256)
+// Two-phase evaluation for software-pipelined loops: `begin` does the range reductions of the R rows a lane owns and issues the R
+// table reads, `poly` is independent of the reads, `end` consumes them - so a loop can keep R lookups in flight.
 template <typename T> struct KappaPend { T s; T lin; int ni; T tabv; };
 // FOLDED (RBF only): the column norm a_j is not added here - the caller has folded 2^(a_j/T) into the column operand.
-template <typename T, int KIND, bool CLAMP, bool FOLDED = false>
-__device__ __forceinline__ KappaPend<T> kappa_hot_begin(T gram, T aj, const double* __restrict__ tab) {
-    KappaPend<T> k;
-    T x64;
-    if (KIND == CGLB_RBF) {
-        x64 = FOLDED ? gram : gram + aj;
-        k.lin = T(1);
-    } else {
-        const T d2 = tfma<T>(T(-2), gram, aj);
-        const T r = sqrt_hot(d2);
-        k.lin = tfma<T>(r, T(CGLB_LN2 / CGLB_HOT_UNITS), T(1));
-        x64 = -r;
-    }
-    if (sizeof(T) == 4) {  // fp32 has a hardware exp2: no table
-        k.s = x64; k.ni = 0; k.tabv = T(0);
-        return k;
-    }
-    if (CLAMP) x64 = tmax<T>(x64, T(-CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE));
-    const T n = __builtin_rint(x64);
-    k.s = x64 - n;
-    k.ni = (int)n;
-    k.tabv = (T)tab[k.ni & (CGLB_TAB_SIZE - 1)];
-    return k;
-}
-// Batched `begin` for the R rows a lane owns.  With CGLB_EXP_FLOOR (fp64) the range reduction is the floor/fract form and the R
-// round-down adds share one rounding-mode window (floor_magic*); the table passed in must then be the floor table (2^((k+1/2)/T)).
-template <typename T, int KIND, bool CLAMP, bool FOLDED, int R>
+template <typename T, int KIND, bool CLAMP, bool FOLDED, int PREC, int R>
 __device__ __forceinline__ void kappa_hot_begin_batch(const T (&gram)[R], T aj, const double* __restrict__ tab, KappaPend<T> (&kp)[R]) {
-#if CGLB_EXP_FLOOR
     if constexpr (sizeof(T) == 8) {
         double x[R], t[R];  // RBF: x = exponent; Matern: x = r (the exponent is -r)
 #pragma unroll
@@ -366,43 +276,40 @@ __device__ __forceinline__ void kappa_hot_begin_batch(const T (&gram)[R], T aj, 
                 if (CLAMP) x[r] = tmax<double>(x[r], -CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE);
             } else {
                 const double d2 = tfma<double>(-2.0, gram[r], aj);
-                x[r] = sqrt_hot(d2);
+                x[r] = sqrt_hot<PREC>(d2);
                 kp[r].lin = tfma<double>(x[r], CGLB_LN2 / CGLB_HOT_UNITS, 1.0);
                 if (CLAMP) x[r] = tmin<double>(x[r], CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE);
             }
         }
         constexpr bool NEG = KIND != CGLB_RBF;
-        if constexpr (R % 4 == 0) {
-#pragma unroll
-            for (int r = 0; r < R; r += 4) floor_magic4<NEG>(x[r], x[r + 1], x[r + 2], x[r + 3], t[r], t[r + 1], t[r + 2], t[r + 3]);
-        } else if constexpr (R % 2 == 0) {
-#pragma unroll
-            for (int r = 0; r < R; r += 2) floor_magic2<NEG>(x[r], x[r + 1], t[r], t[r + 1]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) floor_magic1<NEG>(x[r], t[r]);
-        }
+        floor_magic<NEG, R>(x, t);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             kp[r].s = __builtin_amdgcn_fract(NEG ? -x[r] : x[r]);
             kp[r].ni = __double2loint(t[r]);
             kp[r].tabv = tab[kp[r].ni & (CGLB_TAB_SIZE - 1)];
         }
-        return;
-    }
-#endif
+    } else {  // fp32 has a hardware exp2: no table
 #pragma unroll
-    for (int r = 0; r < R; ++r) kp[r] = kappa_hot_begin<T, KIND, CLAMP, FOLDED>(gram[r], aj, tab);
+        for (int r = 0; r < R; ++r) {
+            if (KIND == CGLB_RBF) {
+                kp[r].s = FOLDED ? gram[r] : gram[r] + aj;
+                kp[r].lin = T(1);
+            } else {
+                const T rr = sqrt_hot<PREC>(tfma<T>(T(-2), gram[r], aj));
+                kp[r].lin = tfma<T>(rr, T(CGLB_LN2 / CGLB_HOT_UNITS), T(1));
+                kp[r].s = -rr;
+            }
+            kp[r].ni = 0;
+            kp[r].tabv = T(0);
+        }
+    }
 }
 // polynomial part (independent of the table read): overwrites k.s with P(s) [* lin for Matern]
-template <typename T, int KIND> __device__ __forceinline__ void kappa_hot_poly(KappaPend<T>& k) {
+template <typename T, int KIND, int PREC> __device__ __forceinline__ void kappa_hot_poly(KappaPend<T>& k) {
     T p;
-    if (sizeof(T) == 4) p = (T)__builtin_amdgcn_exp2f((float)k.s * (1.0f / (float)CGLB_TAB_SIZE));
-#if CGLB_EXP_FLOOR
-    else p = exp2_tab_poly_floor<T>(k.s);
-#else
-    else p = exp2_tab_poly<T>(k.s);
-#endif
+    if constexpr (sizeof(T) == 4) p = (T)__builtin_amdgcn_exp2f((float)k.s * (1.0f / (float)CGLB_TAB_SIZE));
+    else p = exp2_tab_poly<PREC>(k.s);
     if (KIND != CGLB_RBF) p *= k.lin;
     k.s = p;
 }
@@ -411,21 +318,21 @@ template <typename T, int KIND> __device__ __forceinline__ T kappa_hot_end(const
     return (T)(exp2_tab_scale((double)k.tabv, k.ni) * (double)k.s);
 }
 // one pair, same arithmetic as the batched form (ragged tails of the symmetric kernel)
-template <typename T, int KIND, bool CLAMP, bool FOLDED>
+template <typename T, int KIND, bool CLAMP, bool FOLDED, int PREC>
 __device__ __forceinline__ T kappa_hot_single(T gram, T aj, const double* __restrict__ tab) {
     T g1[1] = {gram};
     KappaPend<T> kp[1];
-    kappa_hot_begin_batch<T, KIND, CLAMP, FOLDED, 1>(g1, aj, tab, kp);
-    kappa_hot_poly<T, KIND>(kp[0]);
+    kappa_hot_begin_batch<T, KIND, CLAMP, FOLDED, PREC, 1>(g1, aj, tab, kp);
+    kappa_hot_poly<T, KIND, PREC>(kp[0]);
     return kappa_hot_end<T, KIND>(kp[0]);
 }
 
-// gradient factor from an exact squared distance in hot units (RBF: d2h = 64 d2s; Matern32: d2h = 4096 d2s)
-template <typename T, int KIND, bool CLAMP> __device__ __forceinline__ T hfac_hot_from_d2(T d2h, const double* __restrict__ tab) {
+// gradient factor from an exact squared distance in hot units (RBF: d2h = 256 d2s; Matern32: d2h = 65536 d2s)
+template <typename T, int KIND, bool CLAMP, int PREC> __device__ __forceinline__ T hfac_hot_from_d2(T d2h, const double* __restrict__ tab) {
     if (KIND == CGLB_RBF) {
-        return exp2_tab<CLAMP>(T(-0.5) * d2h, tab);
+        return exp2_tab<CLAMP, PREC>(T(-0.5) * d2h, tab);
     } else {
-        return T(3) * exp2_tab<CLAMP>(-sqrt_pos(d2h), tab);
+        return T(3) * exp2_tab<CLAMP, PREC>(-sqrt_pos(d2h), tab);
     }
 }
 // cooperative load of the exp2 table into LDS (call from every thread of the block, before any early exit)

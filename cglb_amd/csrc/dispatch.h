@@ -1,6 +1,7 @@
 // Compile-time dispatch over element type, kernel kind and padded input dimension.
 #pragma once
 #include "cglb_internal.h"
+#include "devmath.h"
 
 // BODY sees: typename T, constexpr int KIND, constexpr int DP
 #define CGLB_DISPATCH_DP(dp, ...)                                           \
@@ -25,6 +26,13 @@
 #define CGLB_DISPATCH_T(dtype, ...)                                         \
     if ((dtype) == CGLB_F64) { using T = double; __VA_ARGS__; }             \
     else { using T = float; __VA_ARGS__; }
+
+// BODY additionally sees constexpr int PREC (devmath.h precision level).  Use inside a function template on T: fp32 has a hardware
+// exp2 / sqrt and builds one instance only.
+#define CGLB_DISPATCH_PREC(c, ...)                                                                                   \
+    if constexpr (sizeof(T) == 4) { constexpr int PREC = CGLB_PREC_EXACT; __VA_ARGS__; }                             \
+    else if ((c)->precision == CGLB_PREC_EXACT) { constexpr int PREC = CGLB_PREC_EXACT; __VA_ARGS__; }               \
+    else { constexpr int PREC = CGLB_PREC_FAST; __VA_ARGS__; }
 
 #define CGLB_DISPATCH_ALL(c, ...) \
     CGLB_DISPATCH_T((c)->dtype, CGLB_DISPATCH_KIND((c)->kind, CGLB_DISPATCH_DP((c)->Dp, __VA_ARGS__)))

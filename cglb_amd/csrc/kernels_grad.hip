@@ -18,7 +18,7 @@
 //   SYM = true : the square block rows x rows.  The form is symmetric under i <-> j, so only columns at or beyond the
 //                block's first row are visited: the diagonal 256R x 256R block in full with w = u_i v_j, everything to its
 //                right once with w = u_i v_j + u_j v_i  (halves the pair evaluations).
-template <typename T, int KIND, int DP, int R, bool SYM>
+template <typename T, int KIND, int DP, int R, bool SYM, int PREC>
 __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsRow, const T* __restrict__ uRow, const T* __restrict__ vRow,
                                                        int64_t nrows, const T* __restrict__ XsCol, const T* __restrict__ vCol,
                                                        const T* __restrict__ uCol, int64_t ncols, int64_t jchunk, int64_t blk0,
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
             }
             T w = ui[k] * vj;
             if (SYM) w = tfma<T>(vi[k], wu, w);
-            const T hv = hfac_hot_from_d2<T, KIND, true>(d2, tab) * w;
+            const T hv = hfac_hot_from_d2<T, KIND, true, PREC>(d2, tab) * w;
 #pragma unroll
             for (int d = 0; d < DP; ++d) acc[k][d] = tfma<T>(hv, sq[d], acc[k][d]);
         }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
 // with x_jd and x_jd^2 both wave-uniform scalar operands: 2 D + 1 accumulate instructions per pair as before, ~38 instead of 46 in all.
 // The expansion cancels when |x_d| >> |x_id - x_jd| for the pairs that carry weight (lengthscale far below the data range): the
 // operands are centred, so the loss is ~log10((range / l)^2) of 16 digits - irrelevant against the 1e-8 the optimiser needs.
-template <typename T, int KIND, int DP, int R>
+template <typename T, int KIND, int DP, int R, int PREC>
 __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict__ Xh, const T* __restrict__ Xhsq, const T* __restrict__ ah,
                                                             const T* __restrict__ u, const T* __restrict__ v, int64_t row0, int64_t n,
                                                             int64_t jchunk, int64_t blk0, int rb_stride, int rb_offset,
@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict_
             T g = aseed[k];
 #pragma unroll
             for (int d = 0; d < DP; ++d) g = tfma<T>(xi[k][d], xj[d], g);
-            earg[k] = (KIND == CGLB_RBF) ? g + aj : sqrt_hot(tfma<T>(T(-2), g, aj));  // RBF: exponent; Matern: r (exponent -r)
+            earg[k] = (KIND == CGLB_RBF) ? g + aj : sqrt_hot<PREC>(tfma<T>(T(-2), g, aj));  // RBF: exponent; Matern: r (exponent -r)
         }
-        exp2_tab_batch<false, KIND != CGLB_RBF, R>(earg, tab, h);
+        exp2_tab_batch<false, KIND != CGLB_RBF, PREC, R>(earg, tab, h);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             T w = ui[k] * vj;
@@ -242,18 +242,18 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
         if (r.ncols <= 0) continue;
         dim3 grid((unsigned)bx, (unsigned)r.jsplit);
 #define GK_LAUNCH(RR, SYMV)                                                                                                        \
-    hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, SYMV>), grid, dim3(256), 0, c->stream, (const T*)c->Xh + c->r0 * DP,        \
+    hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, SYMV, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh + c->r0 * DP,        \
                        (const T*)u_local, (const T*)v_full + c->r0, c->nloc, (const T*)c->Xh + r.col0 * DP, (const T*)v_full + r.col0, \
                        (const T*)u_local, r.ncols, r.jchunk, blk0, 1, 0, c->gpart, (const double*)c->exp_tab)
 #define GG_LAUNCH(RR)                                                                                                                 \
-    hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,           \
+    hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,     \
                        (const T*)c->xah, (const T*)u_local - c->r0, (const T*)v_full, c->r0, c->nloc, r.jchunk, blk0, 1, 0, c->gpart,     \
                        (const double*)c->exp_tab)
         if (r.sym && c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64) {  // fp32 keeps direct differences: no digits to spare
             // u_local is indexed by global row inside the kernel (row0 + local), hence the shifted base pointer
-            CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GG_LAUNCH(2); } else { GG_LAUNCH(1); });
-        } else if (r.sym) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); }); }
-        else { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); }); }
+            CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GG_LAUNCH(2); } else { GG_LAUNCH(1); }));
+        } else if (r.sym) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); })); }
+        else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); })); }
 #undef GG_LAUNCH
 #undef GK_LAUNCH
         CGLB_LAUNCH_CHECK(c);
@@ -291,15 +291,15 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
     CGLB_TRY(ensure_gpart(c, (size_t)nblk * c->Dp * sizeof(double)));
     dim3 grid((unsigned)bx, (unsigned)jsplit);
 #define GKC_LAUNCH(RR)                                                                                                            \
-    hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, true>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)u_full,  \
+    hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, true, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)u_full,  \
                        (const T*)v_full, c->N, (const T*)c->Xh, (const T*)v_full, (const T*)u_full, c->N, jchunk, (int64_t)0,       \
                        c->par_world, c->par_rank, c->gpart, (const double*)c->exp_tab)
 #define GGC_LAUNCH(RR)                                                                                                               \
-    hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,          \
+    hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,    \
                        (const T*)c->xah, (const T*)u_full, (const T*)v_full, (int64_t)0, c->N, jchunk, (int64_t)0, c->par_world, c->par_rank, \
                        c->gpart, (const double*)c->exp_tab)
-    if (c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64) { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GGC_LAUNCH(2); } else { GGC_LAUNCH(1); }); }
-    else { CGLB_DISPATCH_ALL(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); }); }
+    if (c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GGC_LAUNCH(2); } else { GGC_LAUNCH(1); })); }
+    else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); })); }
 #undef GGC_LAUNCH
 #undef GKC_LAUNCH
     CGLB_LAUNCH_CHECK(c);

@@ -14,7 +14,7 @@
 #include "devmath.h"
 #include "dispatch.h"
 
-template <typename T, int KIND, int DP, int R, bool CLAMP>
+template <typename T, int KIND, int DP, int R, bool CLAMP, int PREC>
 __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ XsRow, const T* __restrict__ xaRow,
                                                          int64_t nrows, const T* __restrict__ Xs,
                                                          const T* __restrict__ xa, const T* __restrict__ p, int64_t col0,
@@ -50,10 +50,10 @@ __global__ __launch_bounds__(256) void kff_matvec_kernel(const T* __restrict__ X
             gram[k] = g;
         }
         KappaPend<T> kp[R];
-        kappa_hot_begin_batch<T, KIND, CLAMP, false, R>(gram, aj, tab, kp);  // the R range reductions share one rounding-mode window
+        kappa_hot_begin_batch<T, KIND, CLAMP, false, PREC, R>(gram, aj, tab, kp);  // the R range reductions share one rounding-mode window
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            kappa_hot_poly<T, KIND>(kp[k]);
+            kappa_hot_poly<T, KIND, PREC>(kp[k]);
             acc[k] = tfma<T>(kappa_hot_end<T, KIND>(kp[k]), pj, acc[k]);
         }
     }
@@ -138,19 +138,23 @@ static int kff_pairs_range(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t 
     *nslots = jsplit;
     dim3 grid((unsigned)bx, (unsigned)jsplit);
 #define KFF_LAUNCH(RR)                                                                                               \
-    do {                                                                                                             \
+    CGLB_DISPATCH_PREC(c, {                                                                                          \
         if (c->exp_clamp)                                                                                            \
-            hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, true>), grid, dim3(256), 0, c->stream, XsRow,      \
+            hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, true, PREC>), grid, dim3(256), 0, c->stream, XsRow, \
                                xaRow, nrows, XsCol, xaCol, p_full, col0, col1, jchunk, part,                          \
                                (const double*)c->exp_tab);                                                          \
         else                                                                                                         \
-            hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, false>), grid, dim3(256), 0, c->stream, XsRow,     \
+            hipLaunchKernelGGL((kff_matvec_kernel<T, KIND, DP, RR, false, PREC>), grid, dim3(256), 0, c->stream, XsRow, \
                                xaRow, nrows, XsCol, xaCol, p_full, col0, col1, jchunk, part,                          \
                                (const double*)c->exp_tab);                                                          \
-    } while (0)
-    if (R == 4) { if constexpr (DP <= 8) KFF_LAUNCH(4); else if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
-    else if (R == 2) { if constexpr (DP <= 16) KFF_LAUNCH(2); else KFF_LAUNCH(1); }
-    else KFF_LAUNCH(1);
+    })
+    if (R == 4) {
+        if constexpr (DP <= 8) { KFF_LAUNCH(4); } else if constexpr (DP <= 16) { KFF_LAUNCH(2); } else { KFF_LAUNCH(1); }
+    } else if (R == 2) {
+        if constexpr (DP <= 16) { KFF_LAUNCH(2); } else { KFF_LAUNCH(1); }
+    } else {
+        KFF_LAUNCH(1);
+    }
 #undef KFF_LAUNCH
     CGLB_LAUNCH_CHECK(c);
     return CGLB_OK;

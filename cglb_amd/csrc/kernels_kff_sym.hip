@@ -30,7 +30,7 @@
 #define SYM_BATCH 16
 typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane side by side: v_pk_fma_f32 (fp32 path)
 
-template <typename T, int KIND, int DP, int R, bool CLAMP>
+template <typename T, int KIND, int DP, int R, bool CLAMP, int PREC>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
                                                       const T* __restrict__ pw, const T* __restrict__ wcol,
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items, int nitems,
@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(
                 }
             }
             KappaPend<T> kp[R];
-            kappa_hot_begin_batch<T, KIND, CLAMP, FOLD, R>(gram, aj, tab, kp);
+            kappa_hot_begin_batch<T, KIND, CLAMP, FOLD, PREC, R>(gram, aj, tab, kp);
             __builtin_amdgcn_sched_barrier(0);  // all R table reads are in flight here ...
 #pragma unroll
-            for (int r = 0; r < R; ++r) kappa_hot_poly<T, KIND>(kp[r]);
+            for (int r = 0; r < R; ++r) kappa_hot_poly<T, KIND, PREC>(kp[r]);
             __builtin_amdgcn_sched_barrier(0);  // ... and are first needed here, R polynomials later
             T tj = 0;
             if (PACKED) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(
             T gram = ai[r];
 #pragma unroll
             for (int d = 0; d < DP; ++d) gram = tfma<T>(PACKED ? (T)xi2[(r / 2) % RP][d][r % 2] : xi[r % RU][d], xj[d], gram);
-            const T kap = kappa_hot_single<T, KIND, CLAMP, FOLD>(gram, aj, tab);  // FOLD: the weight is in pj / applied below
+            const T kap = kappa_hot_single<T, KIND, CLAMP, FOLD, PREC>(gram, aj, tab);  // FOLD: the weight is in pj / applied below
             acc[r] = tfma<T>(kap, pj, acc[r]);
             tj = tfma<T>(kap, pr[r], tj);
         }
@@ -464,14 +464,16 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
             c->k1_events_used += 2;
             HIP_CHECK(c, hipEventRecord(e0, c->stream));
         }
-        if (c->exp_clamp)
-            hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full,
-                               (const T*)nullptr, (const T*)nullptr, row0, n, chunk, (const int2*)c->sym_items, nitems, world, prow_ld, Prow, Pcol,
-                               (const double*)c->exp_tab);
-        else
-            hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah, p_full,
-                               (const T*)c->pwh, (const T*)c->wh, row0, n, chunk, (const int2*)c->sym_items, nitems, world, prow_ld, Prow, Pcol,
-                               (const double*)c->exp_tab);
+        CGLB_DISPATCH_PREC(c, {
+            if (c->exp_clamp)
+                hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true, PREC>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah,
+                                   p_full, (const T*)nullptr, (const T*)nullptr, row0, n, chunk, (const int2*)c->sym_items, nitems, world, prow_ld, Prow,
+                                   Pcol, (const double*)c->exp_tab);
+            else
+                hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false, PREC>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah,
+                                   p_full, (const T*)c->pwh, (const T*)c->wh, row0, n, chunk, (const int2*)c->sym_items, nitems, world, prow_ld, Prow,
+                                   Pcol, (const double*)c->exp_tab);
+        });
         CGLB_LAUNCH_CHECK(c);
         if (e1) HIP_CHECK(c, hipEventRecord(e1, c->stream));
     }

@@ -20,7 +20,9 @@ def test_tiny_problems_match_oracle(N, D, M, kind):
     v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
     res = ctx.objective_and_grad(v, True, 1e-6)
     ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, 1e-6)
-    assert res.steps == ref.steps
+    # a solve run down to 1/2 r^T P r <= 1e-6 sits at the round-off floor of its last steps: when the oracle's statistic lands within
+    # a few 1e-8 of the threshold, a last-bit difference decides one more step (same rule as the duplicate-points test below)
+    assert abs(res.steps - ref.steps) <= 1
     # two converged solves (1/2 r^T P r <= 1e-6) agree to within the CG tolerance itself
     assert res.bound == pytest.approx(ref.bound, rel=1e-9, abs=1e-6)
     refg = orc.objective(kind, X, y, hyp, v.cpu().numpy(), run_cg=False, with_grad=True).grad

@@ -42,6 +42,12 @@ def test_operator_properties_and_row_sample(big):
     rows = slice(12_345, 12_345 + 384)
     ref = orcc.kff_matvec(kind, X, hyp, p.cpu().numpy(), rows.start, rows.stop)            # blocked C oracle, direct differences
     np.testing.assert_allclose(Ap.cpu().numpy()[rows], ref, rtol=0, atol=2e-12 * float(Ap.abs().max()))
+    # precision levels (cglb_set_option "precision"): exact (3e-16 kernel values) against the default fast level (<= 1e-13)
+    ctx.set_option("precision", 0)
+    Ap_exact = ctx.matvec(p)
+    np.testing.assert_allclose(Ap_exact.cpu().numpy()[rows], ref, rtol=0, atol=2e-12 * float(Ap.abs().max()))
+    assert float((Ap_exact - Ap).abs().max()) <= 2e-13 * float(Ap.abs().max())
+    ctx.set_option("precision", 1)
     # plain kernel == symmetric kernel
     ctx.set_option("kff_variant", 0)
     Ap0 = ctx.matvec(p)

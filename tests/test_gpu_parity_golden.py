@@ -93,13 +93,17 @@ def test_bound_and_gradient_at_reference_v(name):
         np.testing.assert_allclose(np.asarray(res.grad[key]), ref, rtol=1e-7, atol=tol, err_msg=key)
 
 
+@pytest.mark.parametrize("precision", [0, 1], ids=["exact", "fast"])
 @pytest.mark.parametrize("name", golden_names())
-def test_implicit_preconditioner_matches_reference(name):
-    """precond_mode = 1: A r and A^T t formed as sigma^-1 L^-1 (K_uf r) / K_fu (L^-T t)/sigma with the tiled pair kernel."""
+def test_implicit_preconditioner_matches_reference(name, precision):
+    """precond_mode = 1: A r and A^T t formed as sigma^-1 L^-1 (K_uf r) / K_fu (L^-T t)/sigma with the tiled pair kernel.
+    Long solves (> 40 steps at tolerances 1e-5 / 1e-6, far below the reference's operating point of 1.0) amplify every
+    perturbation of the operator: +-1 step at the exact precision level (kernel values to 3e-16), +-2 at the fast one (1e-13)."""
     g = load_golden(name)
     from cglb_amd.hip_context import HipContext
     hyp = golden_hypers(g)
     ctx = HipContext(g["X"], g["y"], hyp.Z.shape[0], int(g["kind"]))
+    ctx.set_option("precision", precision)
     ctx.set_option("precond_mode", 1)
     ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, hyp.Z, hyp.jitter)
     ctx.setup()
@@ -108,7 +112,35 @@ def test_implicit_preconditioner_matches_reference(name):
     assert rz == pytest.approx(float(g["rz_test"]), rel=1e-9)
     v = torch.from_numpy(g["v0"]).to(ctx.device).clone()
     res = ctx.objective_and_grad(v, True, float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
-    assert abs(res.steps - int(g["steps"])) <= (0 if int(g["steps"]) <= 40 else 1)
+    assert abs(res.steps - int(g["steps"])) <= (0 if int(g["steps"]) <= 40 else 1 + precision)
     assert res.bound == pytest.approx(float(g["bound"]), rel=1e-6)
     if res.steps == int(g["steps"]) and res.steps <= 20:
         assert res.bound == pytest.approx(float(g["bound"]), rel=1e-9)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_precision_levels_agree(name):
+    """cglb_set_option("precision"): 0 = degree-4 2^x polynomial + two-step sqrt (kernel values to ~3e-16), 1 (default) = degree-3 +
+    one-step sqrt (<= ~1e-13).  The two levels must agree on the operator to 2e-13 and on the golden PCG outputs (exact level:
+    same assertions as the default-level tests above)."""
+    g = load_golden(name)
+    ctx, hyp = make_ctx(g)
+    p = torch.from_numpy(g["r_test"])
+    fast = ctx.matvec(p).cpu().numpy()
+    ctx.set_option("precision", 0)
+    exact = ctx.matvec(p).cpu().numpy()
+    cov = orc.dense_cov(int(g["kind"]), g["X"], hyp)
+    ref = cov @ g["r_test"]
+    np.testing.assert_allclose(exact, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+    np.testing.assert_allclose(fast, exact, rtol=0, atol=2e-13 * np.abs(ref).max())
+    ctx.setup()
+    b = torch.from_numpy(g["y"] - hyp.mean)
+    v, steps, half_rz = ctx.pcg(b, torch.from_numpy(g["v0"]), float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+    ref_steps = int(g["steps"])
+    assert abs(steps - ref_steps) <= (0 if ref_steps <= 40 else 1)
+    vv = torch.from_numpy(g["v"]).to(ctx.device).clone()
+    res = ctx.objective_and_grad(vv, run_cg=False)
+    assert res.bound == pytest.approx(float(g["bound"]), rel=1e-11)
+    for key in ("lengthscales", "variance", "noise", "Z"):
+        refg = g["g_" + key]
+        np.testing.assert_allclose(np.asarray(res.grad[key]), refg, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(refg).max()), err_msg=key)

@@ -95,22 +95,25 @@ def test_two_ranks_on_one_gpu_over_gloo(name):
     np.testing.assert_allclose(grad[D + 3:], fused.grad["Z"].reshape(-1), rtol=1e-8, atol=1e-9)
 
 
+@pytest.mark.parametrize("precision", [0, 1], ids=["exact", "fast"])
 @pytest.mark.parametrize("name", ["rbf_d8_trained", "m32_d3_random", "rbf_d8_restart"])
-def test_world1_cyclic_driver_equals_fused_path(name):
+def test_world1_cyclic_driver_equals_fused_path(name, precision):
     from cglb_amd.distributed import HipSymLocalOps, SymShardedCGLB
     g = load_golden(name)
     args = (float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
     ctx = _mk(g)
+    ctx.set_option("precision", precision)
     v = torch.from_numpy(g["v0"]).to(ctx.device).clone()
     fused = ctx.objective_and_grad(v, True, *args)
     ctx2 = _mk(g)
+    ctx2.set_option("precision", precision)
     drv = SymShardedCGLB(HipSymLocalOps(ctx2))
     drv.v.copy_(torch.from_numpy(g["v0"]).to(ctx2.device))
     res = drv.objective_and_grad(True, *args)
     if fused.steps > 40:
         # long solve: the two drivers sum r^T z in different orders and CG amplifies that round-off (see test_oracle_golden):
-        # the stop test may flip one iteration earlier or later
-        assert abs(res.steps - fused.steps) <= 1
+        # the stop test may flip one iteration earlier or later (two at the fast precision level, whose kernel values carry 1e-13)
+        assert abs(res.steps - fused.steps) <= 1 + precision
         assert res.bound == pytest.approx(fused.bound, rel=1e-7)
         return
     assert res.steps == fused.steps
