@@ -9,7 +9,8 @@ A "step" is ONE objective + gradient evaluation (common terms + PCG from a cold 
 assembly + analytic gradient) of the headline workload: synthetic N = 100 000,
 D = 8, M = 1024, fp64, RBF.  Nothing is cached between steps: v is reset to zero and the common
 terms are recomputed every step.  Inputs are resident in HBM before the timed region.  With N > 1 the
-SAME problem is row-sharded over the ranks (strong scaling) and RCCL collectives run every PCG iteration.
+SAME problem is dealt over the ranks (cyclic-symmetric K_ff blocks + column-sharded Nystrom panel: strong scaling) and three RCCL
+collectives run every PCG iteration.
 
 Rank 0 prints one JSON line (see the `record` dict at the end for the fields).
 """
@@ -143,10 +144,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29555")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # 2-minute collective timeout: a rank that falls out of step ends the job with a non-zero exit instead of hanging it
+        from datetime import timedelta
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(minutes=2))  # "nccl" is RCCL on ROCm
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timedelta(minutes=2))
 
     N, D, M, kind = args.rows, args.dims, args.inducing, args.kernel
     X, y, Z = synthetic_problem(N, D, M, seed=0)
@@ -343,4 +346,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except (FloatingPointError, RuntimeError) as exc:   # non-finite stop statistic / failed HIP or RCCL call: fresh-process semantics
+        print(f"bench.py: rank {os.environ.get('RANK', '0')} failed: {exc}", file=sys.stderr, flush=True)
+        sys.exit(3)

@@ -40,6 +40,7 @@ SIGNATURES = {
     "cglb_precond_apply": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     "cglb_shard_precond_u": (c_int, [c_void_p, c_void_p, c_void_p]),
     "cglb_shard_precond_z": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cglb_shard_precond_z_seg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "cglb_shard_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "cglb_shard_update_v_r": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "cglb_shard_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -58,6 +59,7 @@ SIGNATURES = {
     "cglb_vec_update_v_r": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "cglb_vec_residual": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "cglb_vec_update_p": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "cglb_vec_update_p_seg": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "cglb_vec_axpy": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p]),
     "cglb_shard_obj_phase1_kv": (c_int, [c_void_p, c_void_p, c_void_p]),
     "cglb_shard_obj_w": (c_int, [c_void_p, c_void_p]),

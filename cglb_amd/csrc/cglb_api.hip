@@ -583,6 +583,7 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
     c->var = variance; c->noise = noise; c->mean = mean; c->jitter = jitter;
     HIP_CHECK(c, hipMemcpyAsync(c->Z, Z, (size_t)c->M * c->D * c->esz, hipMemcpyDefault, c->stream));
     c->have_hypers = true;
+    c->pwh_src = nullptr;  // the column weights change with the hypers
     {   // |a_i + a_j + xs_i.xs_j| <= 2 max|xs|^2 (scaled units: octaves for RBF, octaves^2 for Matern).  The unclamped 2^x of
         // the hot loops needs the exponent inside [-1000, 0] octaves (exp2_tab_scale) and its hot-unit integer below 2^30.
         const double ks = (c->kind == CGLB_RBF) ? std::sqrt(CGLB_LOG2E) : CGLB_SQRT3 * CGLB_LOG2E;
@@ -701,6 +702,16 @@ int cglb_shard_precond_z(cglb_ctx* c, const void* r_local, const void* u, void* 
     return precond_z_any(c, r_local, c->w_t, z_local, (double*)rz_partial);
 }
 
+int cglb_shard_precond_z_seg(cglb_ctx* c, const void* r_local, const void* u, void* z_slot, int64_t per) {
+    if (!c || !r_local || !u || !z_slot || per < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    if (per < c->nloc) return cglb_fail(c, CGLB_ERR_BAD_ARG, "precond_z_seg: slice shorter than the local rows");
+    if (c->precond_mode != 0) return cglb_fail(c, CGLB_ERR_STATE, "precond_z_seg needs the stored-panel preconditioner (precond_mode 0)");
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_TRY(launch_tri_apply(c, u, c->w_t));
+    return launch_precond_z(c, r_local, c->w_t, z_slot, nullptr, (char*)z_slot + (size_t)per * c->esz);
+}
+
 int cglb_shard_dot(cglb_ctx* c, const void* a_local, const void* b_local, void* out) {
     if (!c || !a_local || !b_local || !out) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     HIP_CHECK(c, hipSetDevice(c->device));
@@ -755,6 +766,12 @@ int cglb_vec_update_p(cglb_ctx* c, int64_t n, void* p, const void* z, const void
     if (!c || !p || !z || !new_rz || !rz || n < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
     HIP_CHECK(c, hipSetDevice(c->device));
     return launch_update_p(c, p, z, (const double*)new_rz, (const double*)rz, restart, n);
+}
+int cglb_vec_update_p_seg(cglb_ctx* c, int64_t n, int64_t per, int world, void* p, const void* zseg, void* new_rz, const void* rz, int restart) {
+    if (!c || !p || !zseg || !new_rz || !rz || n <= 0 || per <= 0 || world <= 0 || (int64_t)world * per < n)
+        return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return launch_update_p_seg(c, p, zseg, n, per, world, (double*)new_rz, (const double*)rz, restart);
 }
 int cglb_vec_axpy(cglb_ctx* c, int64_t n, double alpha, const void* x, void* y) {
     if (!c || !x || !y || n < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;

@@ -41,6 +41,7 @@ struct cglb_ctx {
     int chol_mode = 1;                   // 1: blocked LDS Cholesky (kernels_chol.hip), 0: rocSOLVER potrf
     int precond_mode = 0;                // 0: stored panel A (reference form), 1: implicit K_uf products
     void *Xhsq = nullptr;  // Xh squared element-wise: second-moment operand of the Gram-form gradient pass (kernels_grad.hip)
+    const void* pwh_src = nullptr;       // vector whose weighted copy pwh currently holds (set by update_p, consumed once by the next symmetric mat-vec)
     void *wh = nullptr, *pwh = nullptr;  // RBF column weights 2^(xah_j/T) and the weighted operand p_j * wh_j of the symmetric mat-vec (length N)
     void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/T octave, T = 2^CGLB_TAB_BITS (devmath.h exp2_tab)
     double* exp_tab = nullptr;           // device table 2^(k/T) or 2^((k+1/2)/T) (CGLB_EXP_FLOOR), k < T = 2^CGLB_TAB_BITS, exponent pre-compensated (devmath.h)
@@ -169,7 +170,8 @@ int launch_axpy(cglb_ctx* c, void* y, double alpha, const void* x, int64_t n);
 int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart, int64_t n = -1);
 int launch_gemv_u(cglb_ctx* c, const void* r_local, void* u_out);               // u = A_loc r
 int launch_tri_apply(cglb_ctx* c, const void* u, void* t_out);                  // t = LB^-T LB^-1 u
-int launch_precond_z(cglb_ctx* c, const void* r_local, const void* t, void* z_local, double* rz_slot);
+int launch_precond_z(cglb_ctx* c, const void* r_local, const void* t, void* z_local, double* rz_slot, void* rz_slot_T = nullptr);
+int launch_update_p_seg(cglb_ctx* c, void* p, const void* zseg, int64_t n, int64_t per, int world, double* new_rz_out, const double* rz, int restart);
 int launch_sub_scalar(cglb_ctx* c, void* out, const void* y_local, double mean, int64_t n);  // e = y - mean
 int launch_tri_clean(cglb_ctx* c, void* Mc, int keep_lower);   // zero the other strict triangle
 int launch_transpose(cglb_ctx* c, const void* src, void* dst); // M x M

@@ -444,10 +444,15 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     const int grid = (nitems + 3) / 4;
     if (grid > 0) {
         if (!c->exp_clamp && KIND == CGLB_RBF) {  // folded column norm: pre-weight the operand over the columns of this block
-            hipLaunchKernelGGL((weight_operand_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, p_full + row0,
-                               (const T*)c->wh + row0, n, (T*)c->pwh + row0);
-            CGLB_LAUNCH_CHECK(c);
+            // (skipped when the update_p kernel that produced exactly this vector has already written the weighted copy)
+            const bool have = c->pwh_src == (const void*)p_full && row0 == 0 && n == c->N;
+            if (!have) {
+                hipLaunchKernelGGL((weight_operand_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, p_full + row0,
+                                   (const T*)c->wh + row0, n, (T*)c->pwh + row0);
+                CGLB_LAUNCH_CHECK(c);
+            }
         }
+        c->pwh_src = nullptr;  // single use: the vector may be modified by the caller afterwards
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->k1_profile) {  // in-situ timing of the dominant kernel (cglb_get_stat)
             if (c->k1_events_used + 2 > c->k1_events.size()) {

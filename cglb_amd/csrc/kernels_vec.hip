@@ -83,21 +83,67 @@ int launch_residual(cglb_ctx* c, void* r, const void* b, const void* Kv, int64_t
 }
 
 // ---- p = z + p * new_rz / rz  (or p = z on restart) --------------------------------------------------------
+// wh != null (RBF, unclamped range): the pre-weighted operand pw = p * wh of the symmetric pair kernel (folded column norm,
+// kernels_kff_sym.hip) is written in the same pass, so the next mat-vec needs no separate weighting launch.
 template <typename T>
 __global__ __launch_bounds__(256) void update_p_kernel(T* __restrict__ p, const T* __restrict__ z, int64_t n,
-                                                       const double* __restrict__ new_rz, const double* __restrict__ rz, int restart) {
+                                                       const double* __restrict__ new_rz, const double* __restrict__ rz, int restart,
+                                                       const T* __restrict__ wh, T* __restrict__ pw) {
     const T beta = restart ? T(0) : (T)(new_rz[0] / rz[0]);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        p[i] = restart ? z[i] : tfma<T>(beta, p[i], z[i]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T pi = restart ? z[i] : tfma<T>(beta, p[i], z[i]);
+        p[i] = pi;
+        if (wh) pw[i] = pi * wh[i];
+    }
+}
+
+// wh/pw of the fused weighting: only for a full-length vector (all N rows) of a context whose symmetric kernel folds the column norm
+static inline bool fuse_weights(const cglb_ctx* c, int64_t n) {
+    return c->kind == CGLB_RBF && !c->exp_clamp && c->have_hypers && n == c->N;
 }
 
 int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart, int64_t n) {
     if (n < 0) n = c->nloc;
     if (n == 0) return CGLB_OK;
     const int grid = vec_grid(n, 256);
+    const bool fw = fuse_weights(c, n);
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((update_p_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (T*)p, (const T*)z,
-                                                 n, new_rz, rz, restart));
+                                                 n, new_rz, rz, restart, fw ? (const T*)c->wh : (const T*)nullptr, (T*)c->pwh));
     CGLB_LAUNCH_CHECK(c);
+    c->pwh_src = fw ? p : nullptr;  // consumed (and cleared) by the next symmetric mat-vec of exactly this vector
+    return CGLB_OK;
+}
+
+// Segmented form for the cyclic multi-GPU driver: z arrives all-gathered in `world` slices of per + 1 elements, slice g = rank g's
+// rows [g*per, (g+1)*per) followed by ONE extra element: that rank's partial of r^T z over its own rows.  new_rz = the sum of the
+// `world` partials in rank order - every rank adds the same numbers in the same order, so the stop test of the host loop
+// (conjugate_gradient.py:65) is taken on a value that is identical on all ranks BY CONSTRUCTION (it no longer depends on the
+// replicated vector arithmetic staying bit-identical).  Also p = z + p new_rz / rz (:75) and the fused operand weighting.
+template <typename T>
+__global__ __launch_bounds__(256) void update_p_seg_kernel(T* __restrict__ p, const T* __restrict__ zseg, int64_t n, int64_t per, int world,
+                                                           double* __restrict__ new_rz_out, const double* __restrict__ rz, int restart,
+                                                           const T* __restrict__ wh, T* __restrict__ pw) {
+    double nrz = 0.0;
+    for (int g = 0; g < world; ++g) nrz += (double)zseg[(int64_t)g * (per + 1) + per];
+    const T beta = restart ? T(0) : (T)(nrz / rz[0]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T zi = zseg[i + i / per];  // slice g = i / per starts at g * (per + 1)
+        const T pi = restart ? zi : tfma<T>(beta, p[i], zi);
+        p[i] = pi;
+        if (wh) pw[i] = pi * wh[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) new_rz_out[0] = nrz;
+}
+
+int launch_update_p_seg(cglb_ctx* c, void* p, const void* zseg, int64_t n, int64_t per, int world, double* new_rz_out, const double* rz,
+                        int restart) {
+    if (n <= 0 || per <= 0 || world <= 0) return cglb_fail(c, CGLB_ERR_BAD_ARG, "update_p_seg: bad geometry");
+    const int grid = vec_grid(n, 256);
+    const bool fw = fuse_weights(c, n);
+    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((update_p_seg_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (T*)p, (const T*)zseg, n, per,
+                                                 world, new_rz_out, rz, restart, fw ? (const T*)c->wh : (const T*)nullptr, (T*)c->pwh));
+    CGLB_LAUNCH_CHECK(c);
+    c->pwh_src = fw ? p : nullptr;
     return CGLB_OK;
 }
 
@@ -138,7 +184,7 @@ int launch_sub_scalar(cglb_ctx* c, void* out, const void* y_local, double mean, 
 #define GU_ROWS 4
 template <typename T>
 __global__ __launch_bounds__(256) void gemv_u_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ r, int64_t nloc, int M,
-                                                     int64_t chunk, double* __restrict__ upart) {
+                                                     int64_t chunk, double* __restrict__ upart, T* __restrict__ u_direct) {
     __shared__ double smem[GU_ROWS][4];
     const int m0 = blockIdx.x * GU_ROWS;
     const int64_t n0 = (int64_t)blockIdx.y * chunk;
@@ -189,7 +235,9 @@ __global__ __launch_bounds__(256) void gemv_u_kernel(const T* __restrict__ A, in
     __syncthreads();
     if (threadIdx.x < GU_ROWS && m0 + (int)threadIdx.x < M) {
         const int q = threadIdx.x;
-        upart[(int64_t)(m0 + q) * gridDim.y + blockIdx.y] = (smem[q][0] + smem[q][1]) + (smem[q][2] + smem[q][3]);
+        const double tot = (smem[q][0] + smem[q][1]) + (smem[q][2] + smem[q][3]);
+        if (u_direct) u_direct[m0 + q] = (T)tot;  // one column split: this IS u[m], no finalize launch
+        else upart[(int64_t)(m0 + q) * gridDim.y + blockIdx.y] = tot;
     }
 }
 
@@ -220,11 +268,13 @@ int launch_gemv_u(cglb_ctx* c, const void* r_local, void* u_out) {
     }
     dim3 grid((unsigned)((c->M + GU_ROWS - 1) / GU_ROWS), (unsigned)nsplit);
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((gemv_u_kernel<T>), grid, dim3(256), 0, c->stream, (const T*)c->At, c->lda,
-                                                 (const T*)r_local, c->nloc, c->M, chunk, c->gpart));
+                                                 (const T*)r_local, c->nloc, c->M, chunk, c->gpart, nsplit == 1 ? (T*)u_out : (T*)nullptr));
     CGLB_LAUNCH_CHECK(c);
-    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((gemv_u_finalize_kernel<T>), dim3((c->M + 255) / 256), dim3(256), 0, c->stream,
-                                                 (const double*)c->gpart, c->M, nsplit, (T*)u_out));
-    CGLB_LAUNCH_CHECK(c);
+    if (nsplit > 1) {
+        CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((gemv_u_finalize_kernel<T>), dim3((c->M + 255) / 256), dim3(256), 0, c->stream,
+                                                     (const double*)c->gpart, c->M, nsplit, (T*)u_out));
+        CGLB_LAUNCH_CHECK(c);
+    }
     return CGLB_OK;
 }
 
@@ -328,7 +378,16 @@ int launch_precond_z_from(cglb_ctx* c, const void* r_local, const void* Ks_local
     return CGLB_OK;
 }
 
-int launch_precond_z(cglb_ctx* c, const void* r_local, const void* t, void* z_local, double* rz_slot) {
+template <typename T>
+__global__ __launch_bounds__(256) void finalize_sum_T_kernel(const double* __restrict__ partials, int n, T* __restrict__ out, double scale) {
+    __shared__ double smem[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += partials[i];
+    s = block_sum(s, smem);
+    if (threadIdx.x == 0) out[0] = (T)(s * scale);
+}
+
+int launch_precond_z(cglb_ctx* c, const void* r_local, const void* t, void* z_local, double* rz_slot, void* rz_slot_T) {
     const int mchunk = 64;
     const int msplit = (c->M + mchunk - 1) / mchunk;
     if (c->nloc > 0) {
@@ -341,8 +400,13 @@ int launch_precond_z(cglb_ctx* c, const void* r_local, const void* t, void* z_lo
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((precond_z_kernel<T>), dim3(g2), dim3(256), 0, c->stream, (const T*)r_local,
                                                  (const T*)c->tpart, msplit, c->nloc, (T)(1.0 / c->noise), (T*)z_local, c->dotpart));
     CGLB_LAUNCH_CHECK(c);
-    if (rz_slot) {  // callers that form r^T z themselves (cyclic multi-GPU driver) pass no slot
+    if (rz_slot) {  // callers that form r^T z themselves pass no slot
         hipLaunchKernelGGL(finalize_sum_kernel2, dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, g2, rz_slot, 1.0 / c->noise);
+        CGLB_LAUNCH_CHECK(c);
+    }
+    if (rz_slot_T) {  // partial r^T z in the vector's element type: the extra element of this rank's all-gather slice
+        CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((finalize_sum_T_kernel<T>), dim3(1), dim3(256), 0, c->stream, (const double*)c->dotpart, g2,
+                                                     (T*)rz_slot_T, 1.0 / c->noise));
         CGLB_LAUNCH_CHECK(c);
     }
     return CGLB_OK;

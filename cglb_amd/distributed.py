@@ -266,6 +266,8 @@ class SymLocalOps(LocalOps):
     def vec_residual(self, n, r, b, Kv): raise NotImplementedError
     def vec_update_p(self, n, p, z, new_rz, rz, restart: bool): raise NotImplementedError
     def vec_axpy(self, n, alpha, x, y): raise NotImplementedError
+    def precond_z_seg(self, r_local, u, z_slot, per: int): raise NotImplementedError
+    def vec_update_p_seg(self, n, per: int, world: int, p, zseg, new_rz, rz, restart: bool): raise NotImplementedError
     def obj_phase1_kv(self, Kv_local, u_out): raise NotImplementedError
     def obj_w(self, w_local_out): raise NotImplementedError
     def obj_phase3_cyclic(self, v_full, u_full, sc, aw, grad_out): raise NotImplementedError
@@ -284,6 +286,8 @@ class HipSymLocalOps(HipLocalOps, SymLocalOps):
     def vec_residual(self, n, r, b, Kv): self._ck(self.lib.cglb_vec_residual(self.h, int(n), self._p(r), self._p(b), self._p(Kv)))
     def vec_update_p(self, n, p, z, new_rz, rz, restart): self._ck(self.lib.cglb_vec_update_p(self.h, int(n), self._p(p), self._p(z), self._p(new_rz), self._p(rz), int(restart)))
     def vec_axpy(self, n, alpha, x, y): self._ck(self.lib.cglb_vec_axpy(self.h, int(n), float(alpha), self._p(x), self._p(y)))
+    def precond_z_seg(self, r_local, u, z_slot, per): self._ck(self.lib.cglb_shard_precond_z_seg(self.h, self._p(r_local), self._p(u), self._p(z_slot), int(per)))
+    def vec_update_p_seg(self, n, per, world, p, zseg, new_rz, rz, restart): self._ck(self.lib.cglb_vec_update_p_seg(self.h, int(n), int(per), int(world), self._p(p), self._p(zseg), self._p(new_rz), self._p(rz), int(restart)))
     def obj_phase1_kv(self, Kv_local, u_out): self._ck(self.lib.cglb_shard_obj_phase1_kv(self.h, self._p(Kv_local), self._p(u_out)))
     def obj_w(self, w_local_out): self._ck(self.lib.cglb_shard_obj_w(self.h, self._p(w_local_out)))
     def obj_phase3_cyclic(self, v_full, u_full, sc, aw, grad_out): self._ck(self.lib.cglb_shard_obj_phase3_cyclic(self.h, self._p(v_full), self._p(u_full), self._p(sc), self._p(aw), self._p(grad_out)))
@@ -297,10 +301,14 @@ class SymShardedCGLB:
       one all-reduce (N elements) gives every rank the full product.  Work per rank is N^2/(2G) pair evaluations, against
       ~N^2/G for row sharding (where only the diagonal block of a shard is symmetric).
     * p, Ap, v, r, b live in full on every rank; their O(N) updates are done redundantly (identical inputs, identical
-      kernels -> identical bits, so all ranks take the same branch of the stop test).
+      kernels -> identical bits).
     * The Nystrom panel A stays column-sharded over contiguous rows [r0, r1): u = A r is all-reduced (M elements) and the
-      preconditioned residual z is all-gathered (N/G elements per rank).
-    Collectives per PCG iteration: all-reduce(N), all-reduce(M), all-gather(N/G) — three instead of four, no scalar ones.
+      preconditioned residual z is all-gathered in slices of per + 1 elements: the extra element of a slice carries that rank's
+      partial of r^T z over its own rows.  r^T P r - the scalar the host's stop test reads (conjugate_gradient.py:65) - is the sum
+      of those `world` partials in rank order, so every rank derives it from the SAME gathered numbers: the loop's control flow is
+      identical on all ranks by construction, even if a replicated vector should ever differ in a bit between ranks (which would
+      otherwise strand the ranks in different collectives).  A non-finite value raises on every rank together.
+    Collectives per PCG iteration: all-reduce(N), all-reduce(M), all-gather(N/G + 1) - three instead of four, no scalar ones.
     """
 
     def __init__(self, ops: SymLocalOps, comm: Optional[Comm] = None):
@@ -317,7 +325,8 @@ class SymShardedCGLB:
         z = lambda n, d=dt: torch.zeros(max(n, 1), dtype=d, device=dev)
         N, per = self.N, self.per
         self.v, self.p, self.r, self.Ap, self.Kv, self.b = z(N), z(N), z(N), z(N), z(N), z(N)
-        self.zbuf, self.ubuf = z(G * per), z(G * per)   # all-gather targets (padded to equal slices)
+        self.zseg = z(G * (per + 1))                    # all-gather target of z: G slices of per rows + 1 partial of r^T z
+        self.ubuf = z(G * per)                          # all-gather target of u = w + v/2 (gradient phase)
         self.u, self.aw = z(self.M), z(self.M)
         self.rz, self.rz_new, self.pAp, self.scratch = z(1, torch.float64), z(1, torch.float64), z(1, torch.float64), z(1, torch.float64)
         self.sc = z(8, torch.float64)
@@ -360,20 +369,27 @@ class SymShardedCGLB:
         self.ops.matvec_cyclic(x_full, out_full)    # rank 0's partial carries the noise term
         self.comm.allreduce(out_full)
 
-    def _precond(self, rz_out):
-        """z = P r (full, gathered into zbuf[:N]); rz_out = r^T z."""
-        ops = self.ops
+    def _precond_and_direction(self, rz_new, rz_old, restart: bool):
+        """z = P r (conjugate_gradient.py:73), gathered in segments; then rz_new = r^T z from the gathered partials and
+        p = z + p rz_new / rz_old, or p = z (:75)."""
+        ops, per, G = self.ops, self.per, self.comm.world
         r_loc = self.r[self.r0:self.r1]
         ops.precond_u(r_loc, self.u)
         self.comm.allreduce(self.u)
-        ops.precond_z(r_loc, self.u, self._own(self.zbuf), None)   # r^T z is formed below over the gathered z (no scalar collective)
-        self.comm.allgather_inplace(self.zbuf, self.per)
-        ops.vec_dot(self.N, self.r, self.zbuf[: self.N], rz_out)
+        slot = self.zseg[self.comm.rank * (per + 1): (self.comm.rank + 1) * (per + 1)]
+        ops.precond_z_seg(r_loc, self.u, slot, per)
+        self.comm.allgather_inplace(self.zseg, per + 1)
+        ops.vec_update_p_seg(self.N, per, G, self.p, self.zseg, rz_new, rz_old, restart)
+
+    @staticmethod
+    def _check_finite(rz: float, where: str):
+        if not np.isfinite(rz):
+            # the value is a function of all-gathered numbers only: every rank sees the same one and leaves the loop here together
+            raise FloatingPointError(f"r^T P r is not finite {where}: {rz}")
 
     def pcg(self, max_error=1.0, max_cg_iter=100, restart_cg_iter=40) -> Tuple[int, float]:
         """conjugate_gradient.py:41-86 on replicated full vectors; v is updated in place."""
         ops, N = self.ops, self.N
-        zf = self.zbuf[:N]
         ops.rhs_full(self.b)
         ops.vec_dot(N, self.v, self.v, self.scratch)
         if float(self.scratch.item()) == 0.0:
@@ -383,9 +399,9 @@ class SymShardedCGLB:
         else:
             self.matvec(self.v, self.Kv)                           # :57
             ops.vec_residual(N, self.r, self.b, self.Kv)           # :58
-        self._precond(self.rz)                                     # :59
-        ops.vec_update_p(N, self.p, zf, self.rz, self.rz, True)    # :61
+        self._precond_and_direction(self.rz, self.rz, True)        # :59, :61
         rz = float(self.rz.item())
+        self._check_finite(rz, "at the start of the solve")
         i = 0
         ahead = False
         while 0.5 * rz > max_error and i < max_cg_iter:            # :65
@@ -397,17 +413,17 @@ class SymShardedCGLB:
             if restart:
                 self.matvec(self.v, self.Kv)
                 ops.vec_residual(N, self.r, self.b, self.Kv)
-            self._precond(self.rz_new)                             # :73
-            ops.vec_update_p(N, self.p, zf, self.rz_new, self.rz, restart)  # :75
+            self._precond_and_direction(self.rz_new, self.rz, restart)   # :73, :75
             self.rz, self.rz_new = self.rz_new, self.rz            # :76 (the two scalar slots swap roles: no copy kernel)
             # Host test of :65 with look-ahead (same rule as the fused pcg_impl): while the residual is still far above the
             # tolerance the next mat-vec (kernel + all-reduce) is enqueued before the host waits for this iteration's scalar;
-            # if the test then says stop it was wasted work on Ap only.  rz is identical on all ranks -> same decision everywhere.
+            # if the test then says stop it was wasted work on Ap only.  rz comes from gathered partials -> same decision everywhere.
             pending = self._read_scalar_async(self.rz)
             ahead = self.lookahead and (i + 1 < max_cg_iter) and (0.5 * rz > 4.0 * max_error)
             if ahead:
                 self.matvec(self.p, self.Ap)
             rz = pending()
+            self._check_finite(rz, f"after iteration {i}")
             i += 1
         return i, 0.5 * rz
 

@@ -90,6 +90,10 @@ int cglb_shard_precond_u(cglb_ctx* ctx, const void* r_local, void* u_partial /* 
 int cglb_shard_precond_z(cglb_ctx* ctx, const void* r_local, const void* u /* dev [m], reduced */,
                          void* z_local, void* rz_partial /* dev [1], or NULL when the caller forms r^T z itself */);
 
+/* segmented form for the cyclic multi-GPU path: z_slot is this rank's slice of the all-gather buffer, dev [per + 1]: z for the local
+ * rows in [0, n_local) and, in element `per`, this rank's partial of r^T z over its own rows (in the vector element type). */
+int cglb_shard_precond_z_seg(cglb_ctx* ctx, const void* r_local, const void* u /* dev [m], reduced */, void* z_slot, int64_t per);
+
 /* ---- vector primitives of the PCG loop (conjugate_gradient.py:67-75), for the sharded host loop ---- */
 /* dot: out[0] = sum_i a_i b_i over local rows (dev scalar, deterministic order). */
 int cglb_shard_dot(cglb_ctx* ctx, const void* a_local, const void* b_local, void* out /* dev [1] */);
@@ -146,6 +150,10 @@ int cglb_vec_dot(cglb_ctx* ctx, int64_t n, const void* a, const void* b, void* o
 int cglb_vec_update_v_r(cglb_ctx* ctx, int64_t n, void* v, void* r, const void* p, const void* Ap, const void* rz, const void* pAp, int update_r);
 int cglb_vec_residual(cglb_ctx* ctx, int64_t n, void* r, const void* b, const void* Kv);
 int cglb_vec_update_p(cglb_ctx* ctx, int64_t n, void* p, const void* z, const void* new_rz, const void* rz, int restart);
+/* p = z + p * (new_rz / rz) (or p = z) with z all-gathered in `world` slices of per + 1 elements (cglb_shard_precond_z_seg) and
+ * new_rz = the sum, in rank order, of the slices' extra elements: the stop-test scalar is then identical on every rank by
+ * construction.  new_rz: dev double[1], written; rz: dev double[1], the previous value (conjugate_gradient.py:75-76). */
+int cglb_vec_update_p_seg(cglb_ctx* ctx, int64_t n, int64_t per, int world, void* p, const void* zseg, void* new_rz, const void* rz, int restart);
 int cglb_vec_axpy(cglb_ctx* ctx, int64_t n, double alpha, const void* x, void* y); /* y += alpha x */
 /* objective phase 1 with (K_ff + noise I) v already computed for the local rows; phase 2 unchanged; the local slice of
  * w = P r for the all-gather of u = w + v/2; phase 3 with the cyclic share of the N^2 gradient form (u_full gathered). */
@@ -180,7 +188,8 @@ int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
  * "k1_pairs_per_launch": kernel pairs one launch of that kernel evaluates with the current geometry (~N(N+256)/2 on one GPU: the
  * symmetric form visits each unordered pair once) - the unit count of the roofline; "kpart_bytes": size of the partial-sum slabs. */
 int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
-/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" | "sym_order" | "aat_block" | "grad_gram" | "k1_profile" ...;
+/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" | "sym_order" | "aat_block" | "grad_gram" | "k1_profile" |
+ * "precision" (1, default: kernel values to <= 1e-13 relative - degree-3 table polynomial, one-step square root; 0: ~3e-16) ...;
  * returns CGLB_ERR_BAD_ARG if unknown. */
 int cglb_set_option(cglb_ctx* ctx, const char* name, int64_t value);
 

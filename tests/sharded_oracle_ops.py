@@ -177,6 +177,24 @@ class OracleSymLocalOps(OracleLocalOps, SymLocalOps):
     def vec_update_p(self, n, p, z, new_rz, rz, restart): self.update_p(p[:n], z[:n], new_rz, rz, restart)
     def vec_axpy(self, n, alpha, x, y): y[:n] += alpha * x[:n]
 
+    def precond_z_seg(self, r_local, u, z_slot, per):
+        nloc = self.r1 - self.r0
+        part = torch.zeros(1, dtype=torch.float64)
+        self.precond_z(r_local, u, z_slot[:nloc], part)
+        z_slot[per] = part[0]                                # the slice's extra element: this rank's partial of r^T z
+
+    def vec_update_p_seg(self, n, per, world, p, zseg, new_rz, rz, restart):
+        seg = zseg.numpy().reshape(world, per + 1)
+        nrz = 0.0
+        for g in range(world):                               # rank order, like the kernel
+            nrz += float(seg[g, per])
+        z = torch.from_numpy(seg[:, :per].reshape(-1)[:n].copy())
+        if restart:
+            p[:n].copy_(z)
+        else:
+            p[:n].copy_(z + p[:n] * (nrz / float(rz[0])))
+        new_rz[0] = nrz
+
     def obj_phase1_kv(self, Kv_local, u):
         self.e = self.y[self.r0:self.r1] - self.hyp.mean
         self.Kv = Kv_local.numpy().copy()

@@ -103,7 +103,10 @@ def _worker_sym(rank, world, port, name, max_error, max_iter, restart, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("rbf_d8_trained", 2), ("m32_d3_random", 3), ("rbf_d8_restart", 2), ("c1_snelson_like_m32", 2)])
+# world 4 and 8: ragged N (300 rows: 2 row blocks of 256 for 8 ranks -> most ranks own no K_ff block), short and EMPTY panel shards
+# (N = 200 at world 8: per = 25, all ranks used; c1 at world 8 on N = 200), and the > 40-step restart case at world 4
+@pytest.mark.parametrize("name,world", [("rbf_d8_trained", 2), ("m32_d3_random", 3), ("rbf_d8_restart", 2), ("c1_snelson_like_m32", 2),
+                                        ("rbf_d8_restart", 4), ("m32_d3_random", 8), ("c1_snelson_like_m32", 8), ("rbf_d8_warm", 4)])
 def test_cyclic_symmetric_driver_matches_single_process(name, world):
     g = load_golden(name)
     hyp = golden_hypers(g)
@@ -152,3 +155,49 @@ def test_cyclic_driver_lookahead_does_not_change_results(name, max_error):
     assert np.array_equal(out[0][2], out[1][2])
     if max_error is None:
         assert abs(out[0][0] - int(g["steps"])) <= (0 if int(g["steps"]) <= 40 else 1)
+
+
+def _worker_diverge(rank, world, port, name, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from cglb_amd.distributed import Comm, SymShardedCGLB, row_partition
+        from sharded_oracle_ops import OracleSymLocalOps
+
+        class Drifting(OracleSymLocalOps):
+            """Rank 1's replicated vectors drift away from rank 0's: what a single flipped bit in replicated arithmetic would start."""
+            def vec_update_v_r(self, n, v, r, p, Ap, rz, pAp, update_r):
+                super().vec_update_v_r(n, v, r, p, Ap, rz, pAp, update_r)
+                if self.rank == 1:
+                    r[:n] *= 1.0 + 1e-7
+
+        g = load_golden(name)
+        hyp = golden_hypers(g)
+        per, parts = row_partition(g["X"].shape[0], world)
+        drv = SymShardedCGLB(Drifting(int(g["kind"]), g["X"], g["y"], hyp, *parts[rank]), Comm())
+        drv.v.copy_(torch.from_numpy(g["v0"]))
+        drv.setup()
+        steps, half = drv.pcg(float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+        q.put((rank, steps, half))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stop_test_consensus_survives_diverging_replicas():
+    """The stop-test scalar is the rank-ordered sum of all-gathered per-rank partials, so ranks whose replicated vectors have
+    drifted apart still agree on it bit for bit: same step count everywhere, no rank left behind in a collective."""
+    world, name = 2, "rbf_d8_trained"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_diverge, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] and got[0][1] > 0      # same number of steps on both ranks
+    assert got[0][2] == got[1][2]                        # and the very same scalar
