@@ -2,9 +2,12 @@
 cglb/backend/config.py (:45-166), so that the types keep working as dispatch keys.
 
 Difference: the reference initialises inducing points through the third-party `robustgp.ConditionalVariance`
-(config.py:62-65; requirements.txt:15, un-pinned git URL, absent here).  `InducingVariableConfig.init` restates that
-published algorithm (greedy maximisation of the conditional variance == pivoted Cholesky of K_ff, without
-sampling) in numpy; parity with robustgp itself is unpinned.
+(config.py:62-65; requirements.txt:15, un-pinned git URL, absent here).  `InducingVariableConfig.init` hands the selection to
+the kernel callback's device implementation (`select_inducing`: the hip backend's callback runs cglb_select_inducing, the
+greedy maximisation of the conditional variance == pivoted Cholesky of K_ff without sampling, on the GPU).  There is no CPU
+fallback: a plain callable without `select_inducing` is rejected.  The numpy statement of the rule that checks the kernel lives
+in oracle/cglb_oracle.py; parity with robustgp itself is unpinned (its published form shuffles the inputs first, so its first
+pick is a random row where this rule starts from row 0).
 """
 from __future__ import annotations
 
@@ -17,34 +20,10 @@ import numpy as np
 __all__ = [
     "Config", "ModelConfig", "KernelConfig", "SquaredExponentialConfig", "Matern32Config", "CGLBConfig", "CGLBN2MConfig",
     "CGLBNM2Config", "SGPRN2MConfig", "GPRConfig", "SGPRConfig", "InducingVariableConfig", "GPR_CONFIGS", "SGPR_CONFIGS",
-    "KERNEL_CONFIGS", "INDUCING_VARIABLE_CONFIGS", "greedy_conditional_variance",
+    "KERNEL_CONFIGS", "INDUCING_VARIABLE_CONFIGS",
 ]
 
 Data = Tuple[np.ndarray, np.ndarray]
-
-
-def greedy_conditional_variance(X: np.ndarray, M: int, kernel_fn: Callable, jitter: float = 1e-12) -> np.ndarray:
-    """Greedy inducing-point selection: repeatedly take the point with the largest conditional variance
-    given the points chosen so far (the deterministic `sample=False` rule the reference requests,
-    config.py:63).  kernel_fn(x1, x2, full_cov) follows the reference callback (pytorch/interface.py:278-284):
-    x2=None, full_cov=False -> diag; full_cov=True -> matrix.  O(N M^2) time, O(N M) memory."""
-    N = X.shape[0]
-    M = min(M, N)
-    d = np.asarray(kernel_fn(X, None, full_cov=False), dtype=np.float64).reshape(-1) + jitter
-    ci = np.zeros((M, N))
-    chosen = np.zeros(M, dtype=np.int64)
-    chosen[0] = int(np.argmax(d))
-    for m in range(M - 1):
-        j = chosen[m]
-        dj = np.sqrt(d[j])
-        col = np.asarray(kernel_fn(X, X[j:j + 1], full_cov=True), dtype=np.float64).reshape(-1)
-        col[j] += jitter
-        ei = (col - ci[:m].T @ ci[:m, j]) / dj
-        ci[m] = ei
-        d = np.maximum(d - ei * ei, 0.0)
-        d[chosen[: m + 1]] = 0.0  # a chosen point has no conditional variance left
-        chosen[m + 1] = int(np.argmax(d))
-    return X[chosen].copy()
 
 
 class Config:
@@ -80,12 +59,12 @@ Matern32Config = _record("Matern32Config", (SquaredExponentialConfig,), doc="ARD
 
 
 def _inducing_init(self, data: Data, kernel_fn: Callable):
-    # A kernel callback may bring its own device implementation of the same selection rule (the hip backend does:
-    # cglb_select_inducing); a plain callable goes through the generic numpy form above.
+    # The kernel callback brings the device implementation of the selection rule (the hip backend's does: cglb_select_inducing).
     accelerated = getattr(kernel_fn, "select_inducing", None)
-    if accelerated is not None:
-        return accelerated(np.asarray(data[0]), self.num_variables)
-    return greedy_conditional_variance(np.asarray(data[0]), self.num_variables, kernel_fn)
+    if accelerated is None:
+        raise TypeError("InducingVariableConfig.init needs a kernel callback with a `select_inducing(X, M)` method (the hip backend's "
+                        "init kernel runs the greedy conditional-variance selection on the GPU); there is no CPU fallback")
+    return accelerated(np.asarray(data[0]), self.num_variables)
 
 
 InducingVariableConfig = _record("InducingVariableConfig", (Config,), [("num_variables", int)], namespace={"init": _inducing_init},

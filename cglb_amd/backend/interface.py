@@ -16,7 +16,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 import torch
 
-from . import metric
+from . import jsonio, metric
 from .callbacks import Logger
 from .config import CGLBConfig, KernelConfig, Matern32Config, ModelConfig, SGPRConfig, SquaredExponentialConfig
 from .models import (CGLB, GPR, BaseKernel, GaussianLikelihood, InducingPointKernel, LowerBoundCG, PredictCG, ScaleKernel,
@@ -228,23 +228,22 @@ def _optimize_cglb(model: CGLB, dataset, num_steps: int, logger: Logger, optimiz
 
 
 @save.register
-def _save(model: GPR, logdir: str):  # interface.py:546-551 (json_tricks -> plain json with lists)
+def _save(model: GPR, logdir: str):  # interface.py:546-551: json_tricks.dump(model_parameters(model)) -> same encoding (jsonio.py)
     os.makedirs(logdir, exist_ok=True)
-    params = {k: np.asarray(v).tolist() for k, v in model_parameters(model).items()}
+    params = model_parameters(model)
     with open(Path(logdir, "model.json"), "w") as file:
-        json.dump(params, file)
+        jsonio.dump(params, file)
 
 
 @load.register
 def _load(model: GPR, filepath: str):
     """Reads a model.json written by `save` (the reference's torch `load` expects a state_dict and is asymmetric
     with its own `save`; here the pair round-trips)."""
-    with open(filepath) as file:
-        params = json.load(file)
+    params = jsonio.load(filepath)   # decodes the __ndarray__ objects json_tricks / `save` write; plain lists work too
     model.likelihood.noise = params[".likelihood.variance"]
     with torch.no_grad():
-        model.mean_module.constant.copy_(torch.tensor(params[".mean_function.c"], dtype=torch.float64))
-        model.covar_module.inducing_points.copy_(torch.tensor(params[".inducing_variable.Z"], dtype=torch.float64))
+        model.mean_module.constant.copy_(torch.as_tensor(np.asarray(params[".mean_function.c"]), dtype=torch.float64).reshape(()))
+        model.covar_module.inducing_points.copy_(torch.as_tensor(np.asarray(params[".inducing_variable.Z"]), dtype=torch.float64))
     model.covar_module.base_kernel.base_kernel.lengthscale = params[".kernel.lengthscales"]
     model.covar_module.base_kernel.outputscale = params[".kernel.variance"]
     return model

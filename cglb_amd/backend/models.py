@@ -153,6 +153,21 @@ class CGLB(SGPR):
         self._v_vec = self._build_v_vec()
         self._hyper_token = None
 
+    def check_same_data(self, data: Data) -> None:
+        """ValueError unless (x, y) is the training set the HIP context was built on (same shapes and content)."""
+        x, y = data
+        if x is self.train_inputs[0] and y is self.train_targets:
+            return
+        x = torch.as_tensor(x).detach().cpu().to(torch.float64)
+        y = torch.as_tensor(y).detach().cpu().to(torch.float64).reshape(-1)
+        x = x.reshape(x.shape[0], -1) if x.ndim else x.reshape(1, 1)
+        tx, ty = self.train_inputs[0].to(torch.float64), self.train_targets.to(torch.float64).reshape(-1)
+        if x.shape != tx.shape or y.shape != ty.shape:
+            raise ValueError(f"LowerBoundCG was given data of shape {tuple(x.shape)}/{tuple(y.shape)} but the model holds the training set "
+                             f"{tuple(tx.shape)}/{tuple(ty.shape)}: the bound is only defined on the model's own training data")
+        if not (torch.equal(y, ty) and torch.equal(x, tx)):
+            raise ValueError("LowerBoundCG was given data that differs from the model's training set")
+
     def _build_v_vec(self) -> Tensor:  # models.py:59-68
         return torch.zeros((self.hip.N, 1), dtype=self.dtype, device=self.hip.device, requires_grad=False)
 
@@ -281,7 +296,11 @@ class LowerBoundCG(nn.Module):
         return self.likelihood.noise.squeeze()
 
     def forward(self, data: Optional[Tuple[Tensor, Tensor]] = None, *params) -> Tensor:
-        """`data` is accepted for signature parity (models.py:151); the training set lives in the model's HIP context."""
+        """The reference evaluates the bound on the `data` it is given (models.py:151-169); here the training set lives in the
+        model's HIP context, so `data` must be None or that same training set: anything else (a subset, a held-out set) raises
+        instead of silently returning the bound of the training data."""
+        if data is not None:
+            self.model.check_same_data(data)
         ls, var, noise, mean, Z = self.model.hyper_tensors()
         return _BoundFunction.apply(self, ls, var, noise, mean, Z)
 

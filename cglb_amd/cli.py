@@ -21,7 +21,7 @@ from typing import Callable, Tuple
 import click
 import numpy as np
 
-from .backend import BACKENDS, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS, SGPR_CONFIGS
+from .backend import BACKENDS, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS, SGPR_CONFIGS, jsonio
 from .backend.callbacks import Logger
 from .data import synthetic_problem
 
@@ -88,10 +88,10 @@ def create_optimize_fn(backend, dataset: DatasetBundle, logdir: str, num_steps: 
         logs, results = logger.logs, metrics_fn()
         results["id"] = logdir
         logs["id"] = logdir
-        with open(Path(logdir, "results.json"), "w") as f:
-            json.dump(_jsonable(results), f)
+        with open(Path(logdir, "results.json"), "w") as f:   # cli.py:105-109: json_tricks.dump -> same encoding (backend/jsonio.py)
+            jsonio.dump(results, f)
         with open(Path(logdir, "logs.json"), "w") as f:
-            json.dump(_jsonable(logs), f)
+            jsonio.dump(logs, f)
         return results
 
     return optimize_fn

@@ -1,5 +1,6 @@
 // C ABI of libcglb_hip.so: context, common terms (rocSOLVER/rocBLAS for the true dense contractions),
 // preconditioner, PCG loop, objective assembly and analytic gradient.  See include/cglb_hip.h.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -45,13 +46,13 @@ __global__ __launch_bounds__(256) void mat_combine_kernel(T* __restrict__ out, i
 
 // AAt = sum_b slab[b] (fixed order), lower triangle summed and mirrored so the result is exactly symmetric
 template <typename T>
-__global__ __launch_bounds__(256) void slab_reduce_sym_kernel(const T* __restrict__ slabs, int nslab, int M, T* __restrict__ out) {
+__global__ __launch_bounds__(256) void slab_reduce_sym_kernel(const T* __restrict__ slabs, int nslab, int M, T* __restrict__ out, int accumulate) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t mm = (int64_t)M * M;
     if (idx >= mm) return;
     const int i = (int)(idx % M), j = (int)(idx / M);
     if (i < j) return;
-    T s = 0;
+    T s = accumulate ? out[idx] : T(0);  // later groups of slabs continue the running sum of the earlier ones
     for (int b = 0; b < nslab; ++b) s += slabs[(int64_t)b * mm + idx];
     out[idx] = s;
     out[(int64_t)i * M + j] = s;
@@ -140,6 +141,19 @@ inline int grid1d(int64_t n) {
     return (int)g;
 }
 
+// per-call device temporaries: freed on every exit path of the function that owns the holder
+struct DevTemps {
+    std::vector<void*> ptrs;
+    ~DevTemps() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+    int alloc(cglb_ctx* c, void** out, size_t bytes) {
+        *out = nullptr;
+        hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+        if (e != hipSuccess) return cglb_fail(c, CGLB_ERR_HIP, std::string("hipMalloc of a temporary: ") + hipGetErrorString(e));
+        ptrs.push_back(*out);
+        return CGLB_OK;
+    }
+};
+
 int dalloc(cglb_ctx* c, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     HIP_CHECK(c, hipMalloc(p, bytes));
@@ -172,6 +186,10 @@ int setup_local_impl(cglb_ctx* c) {
         HIP_CHECK(c, hipMemcpyAsync(c->Linv, c->Lc, (size_t)M * M * c->esz, hipMemcpyDeviceToDevice, c->stream));
         BLAS_CHECK(c, xtrtri(c->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, M, (T*)c->Linv, M, c->info_dev + 2));
         CGLB_TRY(launch_transpose(c, c->Linv, c->LinvT));
+        rocblas_int info_inv = 0;
+        HIP_CHECK(c, hipMemcpyAsync(&info_inv, c->info_dev + 2, sizeof(info_inv), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        if (info_inv != 0) return cglb_fail(c, CGLB_ERR_NOT_PD, "inverse of L failed: zero pivot " + std::to_string(info_inv));
     }
     // K_uf shard -> A = L^-1 K_uf / sigma  (models.py:196-197, :206).  Column-major view: At (nloc x M) L^T = Kuf^T / sigma.
     if (c->nloc > 0) {
@@ -186,8 +204,14 @@ int setup_local_impl(cglb_ctx* c) {
         const int64_t kc = 2048;
         const int nfull = (int)(c->nloc / kc);
         const int64_t rem = c->nloc - (int64_t)nfull * kc;
-        const int nslab = nfull + (rem > 0 ? 1 : 0);
-        const size_t need = (size_t)nslab * M * M * c->esz;
+        const int nslab_total = nfull + (rem > 0 ? 1 : 0);
+        // The slabs are processed in groups of at most `group` (64 at M = 1024 = 512 MB; fewer for larger M so that a group stays
+        // within ~1 GB): scratch stays bounded for any nloc, and the groups are added to A A^T in order (fixed order: reproducible).
+        int group = (int)(((size_t)1 << 30) / ((size_t)M * M * c->esz));
+        if (group < 4) group = 4;
+        if (group > 64) group = 64;
+        if (group > nslab_total) group = nslab_total;
+        const size_t need = (size_t)group * M * M * c->esz;
         if (need > c->slab_cap) {
             if (c->slabs) HIP_CHECK(c, hipFree(c->slabs));
             c->slabs = nullptr;
@@ -199,22 +223,27 @@ int setup_local_impl(cglb_ctx* c) {
         // Only the lower block triangle is computed (the slab sum below reads i >= j and mirrors): with `bs`-wide blocks that is
         // nb (nb + 1) / 2 of nb^2 block products - 75 % of the flops at M = 1024 with the default bs = 512 (256-wide blocks lose more in GEMM efficiency than they save: 9.6 vs 9.4 ms of setup).
         const int bs = (c->aat_block > 0 && M % c->aat_block == 0 && M >= 2 * c->aat_block) ? c->aat_block : M;
-        for (int bj = 0; bj < M; bj += bs)
-            for (int bi = bj; bi < M; bi += bs) {
-                const T* Ai = At + (int64_t)bi * c->lda;  // columns bi.. of the column-major (nloc x M) view
-                const T* Aj = At + (int64_t)bj * c->lda;
-                T* Cij = slabs + bi + (int64_t)bj * M;
-                if (nfull > 0)
-                    BLAS_CHECK(c, xgemm_sb(c->blas, rocblas_operation_transpose, rocblas_operation_none, bs, bs, (int)kc, &one, Ai, (int)c->lda, kc,
-                                           Aj, (int)c->lda, kc, &zero, Cij, M, (rocblas_stride)M * M, nfull));
-                if (rem > 0)
-                    BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, bs, bs, (int)rem, &one,
-                                        Ai + (int64_t)nfull * kc, (int)c->lda, Aj + (int64_t)nfull * kc, (int)c->lda, &zero,
-                                        Cij + (int64_t)nfull * M * M, M));
-            }
-        hipLaunchKernelGGL((slab_reduce_sym_kernel<T>), dim3(grid1d_full((int64_t)M * M)), dim3(256), 0, c->stream, (const T*)slabs, nslab, M,
-                           (T*)c->AAt);
-        CGLB_LAUNCH_CHECK(c);
+        for (int s0 = 0; s0 < nslab_total; s0 += group) {
+            const int ns = std::min(group, nslab_total - s0);            // slabs of this group
+            const int nf = std::min(ns, std::max(nfull - s0, 0));         // ... of which full 2048-column chunks
+            const bool tail = (s0 + ns == nslab_total) && rem > 0;        // the short last chunk belongs to this group
+            for (int bj = 0; bj < M; bj += bs)
+                for (int bi = bj; bi < M; bi += bs) {
+                    const T* Ai = At + (int64_t)bi * c->lda + (int64_t)s0 * kc;  // columns bi.. of the column-major (nloc x M) view
+                    const T* Aj = At + (int64_t)bj * c->lda + (int64_t)s0 * kc;
+                    T* Cij = slabs + bi + (int64_t)bj * M;
+                    if (nf > 0)
+                        BLAS_CHECK(c, xgemm_sb(c->blas, rocblas_operation_transpose, rocblas_operation_none, bs, bs, (int)kc, &one, Ai, (int)c->lda, kc,
+                                               Aj, (int)c->lda, kc, &zero, Cij, M, (rocblas_stride)M * M, nf));
+                    if (tail)
+                        BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, bs, bs, (int)rem, &one,
+                                            Ai + (int64_t)nf * kc, (int)c->lda, Aj + (int64_t)nf * kc, (int)c->lda, &zero,
+                                            Cij + (int64_t)nf * M * M, M));
+                }
+            hipLaunchKernelGGL((slab_reduce_sym_kernel<T>), dim3(grid1d_full((int64_t)M * M)), dim3(256), 0, c->stream, (const T*)slabs, ns, M,
+                               (T*)c->AAt, s0 > 0 ? 1 : 0);
+            CGLB_LAUNCH_CHECK(c);
+        }
     } else {
         HIP_CHECK(c, hipMemsetAsync(c->AAt, 0, (size_t)M * M * c->esz, c->stream));
     }
@@ -448,7 +477,12 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     g_create_error.clear();
     if (!out) { g_create_error = "out is NULL"; return CGLB_ERR_BAD_ARG; }
     *out = nullptr;
-    if (n_total <= 0 || row_begin < 0 || row_end < row_begin || row_end > n_total || d <= 0 || d > CGLB_MAX_D || m <= 0 ||
+    if (d > CGLB_MAX_D) {
+        g_create_error = "input dimension D = " + std::to_string(d) + " exceeds the supported maximum of " + std::to_string(CGLB_MAX_D) +
+                         " (the pair kernels keep a lane's row operands in registers; see INTEGRATION.md)";
+        return CGLB_ERR_BAD_ARG;
+    }
+    if (n_total <= 0 || row_begin < 0 || row_end < row_begin || row_end > n_total || d <= 0 || m <= 0 ||
         (dtype != CGLB_F64 && dtype != CGLB_F32) || (kernel_kind != CGLB_RBF && kernel_kind != CGLB_MATERN32)) {
         g_create_error = "bad argument to cglb_ctx_create";
         return CGLB_ERR_BAD_ARG;
@@ -665,16 +699,16 @@ int cglb_cross_matvec(cglb_ctx* c, const void* xnew, int64_t n_new, const void* 
     if (n_new == 0) return CGLB_OK;
     HIP_CHECK(c, hipSetDevice(c->device));
     void *xr = nullptr, *xs = nullptr, *xa = nullptr;
-    HIP_CHECK(c, hipMalloc(&xr, (size_t)n_new * c->D * c->esz));
-    HIP_CHECK(c, hipMalloc(&xs, (size_t)n_new * c->Dp * c->esz));
-    HIP_CHECK(c, hipMalloc(&xa, (size_t)n_new * c->esz));
+    DevTemps tmp;  // freed on every path below
+    CGLB_TRY(tmp.alloc(c, &xr, (size_t)n_new * c->D * c->esz));
+    CGLB_TRY(tmp.alloc(c, &xs, (size_t)n_new * c->Dp * c->esz));
+    CGLB_TRY(tmp.alloc(c, &xa, (size_t)n_new * c->esz));
     int rc = CGLB_OK;
     hipError_t e = hipMemcpyAsync(xr, xnew, (size_t)n_new * c->D * c->esz, hipMemcpyDefault, c->stream);
     if (e != hipSuccess) rc = cglb_fail(c, CGLB_ERR_HIP, "copy of xnew failed");
     if (rc == CGLB_OK) rc = launch_prep_scaled(c, xr, n_new, xs, xa, true);  // rows of the pair kernel: hot units
     if (rc == CGLB_OK) rc = launch_cross_matvec(c, xs, xa, n_new, v_full, out);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(xr); (void)hipFree(xs); (void)hipFree(xa);
+    (void)hipStreamSynchronize(c->stream);  // the temporaries are released when `tmp` goes out of scope
     return rc;
 }
 
@@ -875,21 +909,19 @@ int cglb_select_inducing(cglb_ctx* c, const double* lengthscales, double varianc
     const int M = (int)(c->M < c->N ? c->M : c->N);
     long long* chosen_dev = nullptr;
     double* trace_dev = nullptr;
-    HIP_CHECK(c, hipMalloc(&chosen_dev, (size_t)M * sizeof(long long)));
-    hipError_t e = hipMalloc(&trace_dev, sizeof(double));
-    if (e != hipSuccess) { (void)hipFree(chosen_dev); return cglb_fail(c, CGLB_ERR_HIP, hipGetErrorString(e)); }
+    DevTemps tmp;
+    CGLB_TRY(tmp.alloc(c, (void**)&chosen_dev, (size_t)M * sizeof(long long)));
+    CGLB_TRY(tmp.alloc(c, (void**)&trace_dev, sizeof(double)));
     int rc = launch_select_inducing(c, variance, jitter, chosen_dev, Z_out, trace_dev);
     if (rc == CGLB_OK) {
         std::vector<long long> host(M);
-        e = hipMemcpy(host.data(), chosen_dev, (size_t)M * sizeof(long long), hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(host.data(), chosen_dev, (size_t)M * sizeof(long long), hipMemcpyDeviceToHost);
         double tr = 0.0;
         if (e == hipSuccess) e = hipMemcpy(&tr, trace_dev, sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = cglb_fail(c, CGLB_ERR_HIP, hipGetErrorString(e));
         for (int m = 0; m < M; ++m) indices_out[m] = (int64_t)host[m];
         if (trace_out) *trace_out = tr;
     }
-    (void)hipFree(chosen_dev);
-    (void)hipFree(trace_dev);
     return rc;
 }
 
@@ -902,11 +934,12 @@ int cglb_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_ne
     const int M = c->M;
     const int64_t ld = (n_new + 7) & ~(int64_t)7;
     void *xr = nullptr, *xs = nullptr, *xa = nullptr, *t1 = nullptr, *t2 = nullptr;
-    HIP_CHECK(c, hipMalloc(&xr, (size_t)n_new * c->D * c->esz));
-    HIP_CHECK(c, hipMalloc(&xs, (size_t)n_new * c->Dp * c->esz));
-    HIP_CHECK(c, hipMalloc(&xa, (size_t)n_new * c->esz));
-    HIP_CHECK(c, hipMalloc(&t1, (size_t)M * ld * c->esz));
-    HIP_CHECK(c, hipMalloc(&t2, (size_t)M * ld * c->esz));
+    DevTemps tmp;  // freed on every path below
+    CGLB_TRY(tmp.alloc(c, &xr, (size_t)n_new * c->D * c->esz));
+    CGLB_TRY(tmp.alloc(c, &xs, (size_t)n_new * c->Dp * c->esz));
+    CGLB_TRY(tmp.alloc(c, &xa, (size_t)n_new * c->esz));
+    CGLB_TRY(tmp.alloc(c, &t1, (size_t)M * ld * c->esz));
+    CGLB_TRY(tmp.alloc(c, &t2, (size_t)M * ld * c->esz));
     auto body = [&]() -> int {
         HIP_CHECK(c, hipMemcpyAsync(xr, xnew, (size_t)n_new * c->D * c->esz, hipMemcpyDefault, c->stream));
         CGLB_TRY(launch_prep_scaled(c, xr, n_new, xs, xa, true));               // hot units for the pair kernel
@@ -938,8 +971,7 @@ int cglb_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_ne
         return CGLB_OK;
     };
     const int rc = body();
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(xr); (void)hipFree(xs); (void)hipFree(xa); (void)hipFree(t1); (void)hipFree(t2);
+    (void)hipStreamSynchronize(c->stream);  // before `tmp` releases the buffers the kernels use
     return rc;
 }
 

@@ -424,6 +424,12 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     if (need > c->kpart_cap) {
         if (c->kpart) HIP_CHECK(c, hipFree(c->kpart));
         c->kpart = nullptr;
+        c->kpart_cap = 0;
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(c, hipMemGetInfo(&free_b, &total_b));
+        if (need > free_b)  // the partial-sum slabs grow as N^2 / 256 elements per rank: say so instead of failing inside hipMalloc
+            return cglb_fail(c, CGLB_ERR_HIP, "K_ff mat-vec needs " + std::to_string(need >> 20) + " MiB of partial-sum slabs (N^2/256 + N^2/chunk elements per rank) but only " +
+                                                  std::to_string(free_b >> 20) + " MiB of device memory are free: shard the rows over more GPUs");
         HIP_CHECK(c, hipMalloc(&c->kpart, need));
         c->kpart_cap = need;
     }

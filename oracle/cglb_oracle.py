@@ -342,6 +342,37 @@ def gaussian_log_density(x, mu, var):
     return -0.5 * (math.log(2 * math.pi) + np.log(var) + (mu - x) ** 2 / var)
 
 
+# --------------------------------------------------------------------------- inducing-point initialisation
+def greedy_conditional_variance(X: np.ndarray, M: int, kernel_fn: Callable, jitter: float = 1e-12) -> np.ndarray:
+    """Greedy inducing-point selection: repeatedly take the point with the largest conditional variance given the points chosen
+    so far == pivoted Cholesky of K_ff, lowest index on ties - the deterministic `sample=False` rule the reference requests from
+    robustgp.ConditionalVariance (config.py:62-65).  kernel_fn(x1, x2, full_cov) follows the reference callback
+    (pytorch/interface.py:278-284): x2=None, full_cov=False -> diag; full_cov=True -> matrix.  O(N M^2) time, O(N M) memory.
+
+    PARITY UNPINNED: robustgp is third-party (requirements.txt:15, un-pinned git URL) and absent from the container; this restates
+    its published algorithm.  Known difference: as published, ConditionalVariance shuffles the inputs before the greedy pass, so with
+    a constant k(x, x) its FIRST pick is a random row; this statement (and the HIP kernel it checks) starts from row 0.  The later
+    picks are the arg-max of the conditional variance either way.
+    """
+    N = X.shape[0]
+    M = min(M, N)
+    d = np.asarray(kernel_fn(X, None, full_cov=False), dtype=np.float64).reshape(-1) + jitter
+    ci = np.zeros((M, N))
+    chosen = np.zeros(M, dtype=np.int64)
+    chosen[0] = int(np.argmax(d))
+    for m in range(M - 1):
+        j = chosen[m]
+        dj = np.sqrt(d[j])
+        col = np.asarray(kernel_fn(X, X[j:j + 1], full_cov=True), dtype=np.float64).reshape(-1)
+        col[j] += jitter
+        ei = (col - ci[:m].T @ ci[:m, j]) / dj
+        ci[m] = ei
+        d = np.maximum(d - ei * ei, 0.0)
+        d[chosen[: m + 1]] = 0.0  # a chosen point has no conditional variance left
+        chosen[m + 1] = int(np.argmax(d))
+    return X[chosen].copy()
+
+
 # --------------------------------------------------------------------------- synthetic inputs (SURVEY 8d)
 def synthetic_problem(N: int, D: int, M: int, seed: int = 0, dtype=np.float64):
     """Deterministic synthetic regression set: X~N(0,1), y=sin(Xa)+0.1eps z-normalised,

@@ -98,8 +98,12 @@ def test_training_loop_metrics_save_load(tmp_path):
     assert m["test/rmse"] < 0.9                # better than predicting the mean of z-normalised targets
     assert {"loss", "cg/steps", "cg/error", "steps-per-feval", "residual_error-per-feval", "elapsed_time", "params", "iteration"} <= set(logger.logs)
     be.save(model, str(tmp_path))
-    saved = json.load(open(os.path.join(tmp_path, "model.json")))
-    assert set(saved) == set(be.model_parameters(model))
+    from cglb_amd.backend import jsonio
+    saved = jsonio.load(os.path.join(tmp_path, "model.json"))       # json_tricks-shaped reader
+    live = be.model_parameters(model)
+    assert set(saved) == set(live)
+    for k in live:
+        assert np.shape(saved[k]) == np.shape(live[k]) and np.allclose(saved[k], live[k], rtol=1e-15)
     be2, model2, _ = _model("Matern32", M=12, data=data)
     be2.load(model2, os.path.join(tmp_path, "model.json"))
     for k, v in be.model_parameters(model).items():
@@ -167,6 +171,51 @@ def test_solver_and_preconditioner_seams():
         ConjugateGradient()(torch.eye(hip.N, dtype=torch.float64), b, v0, NystromPreconditioner(hip))
 
 
+@pytest.mark.parametrize("kernel,kind", [("rbf", "rbf"), ("Matern32", "matern32")])
+def test_foreign_preconditioner_through_the_open_seam(kernel, kind):
+    """`Preconditioner = Callable[[Tensor], Tuple[Tensor, Tensor]]` (conjugate_gradient.py:22): any callable works, here the identity
+    (plain CG) and a Jacobi scaling, against orc.pcg with the same preconditioner on the dense operator."""
+    from cglb_amd.backend.conjugate_gradient import ConjugateGradient, KernelOperator
+    from cglb_amd.backend.models import LowerBoundCG
+    be, model, (train, _) = _model(kernel, M=16)
+    float(-LowerBoundCG(model)(None))                       # pushes the hypers and runs setup
+    hyp = _hyp_of(model)
+    hip = model.hip
+    N = hip.N
+    cov = orc.dense_cov(kind, train[0], hyp)
+    b_np = train[1] - hyp.mean
+    b = torch.from_numpy(b_np).to(hip.device).reshape(-1, 1)
+    v0 = torch.zeros(N, 1, dtype=torch.float64, device=hip.device)
+    dinv = 1.0 / np.diag(cov)
+    dinv_t = torch.from_numpy(dinv).to(hip.device).reshape(-1, 1)
+    cases = {
+        "identity": (lambda r: (r.clone(), (r * r).sum()), lambda r: (r.copy(), float(r @ r))),
+        "jacobi": (lambda r: (r * dinv_t, (r * r * dinv_t).sum()), lambda r: (r * dinv, float(r @ (r * dinv)))),
+    }
+    for name, (hip_pre, np_pre) in cases.items():
+        for tol, max_iter, restart in ((1e-2, 100, 40), (1e-30, 7, 3)):
+            vout, stats = ConjugateGradient(tol, max_iter, restart)(KernelOperator(hip), b, v0, hip_pre)
+            ref_v, ref_stats = orc.pcg(lambda x: cov @ x, b_np, np.zeros(N), np_pre, tol, max_iter, restart)
+            assert stats.steps == ref_stats.steps, name
+            assert float(stats.residual_error) == pytest.approx(ref_stats.residual_error, rel=1e-6), name
+            np.testing.assert_allclose(vout.cpu().numpy().reshape(-1), ref_v, rtol=0, atol=1e-8 * np.abs(ref_v).max(), err_msg=name)
+            assert float(v0.abs().max()) == 0.0 and vout.shape == v0.shape      # the argument is not mutated (:55)
+
+
+def test_lower_bound_checks_the_data_argument():
+    """The reference evaluates the bound on the data it is given (models.py:151-169): here that must be the model's training set."""
+    from cglb_amd.backend.models import LowerBoundCG
+    be, model, (train, test) = _model("rbf", M=8)
+    lb = LowerBoundCG(model)
+    a = float(-lb(None))
+    model.v_vec.zero_()
+    assert float(-lb((train[0], train[1]))) == pytest.approx(a, rel=1e-12)
+    with pytest.raises(ValueError):
+        lb((train[0][:50], train[1][:50]))
+    with pytest.raises(ValueError):
+        lb((train[0] + 1e-3, train[1]))
+
+
 def test_cli_train_and_metric_roundtrip(tmp_path):
     """Config C1 plumbing (snelson-like, Matern32, M=16, fp64) through the click command tree of cli.py:60-152."""
     from click.testing import CliRunner
@@ -177,8 +226,10 @@ def test_cli_train_and_metric_roundtrip(tmp_path):
     assert r.exit_code == 0, r.output
     for f in ("model.json", "results.json", "logs.json"):
         assert os.path.exists(os.path.join(logdir, f))
-    results = json.load(open(os.path.join(logdir, "results.json")))
-    logs = json.load(open(os.path.join(logdir, "logs.json")))
+    from cglb_amd.backend import jsonio
+    results = jsonio.load(os.path.join(logdir, "results.json"))
+    logs = jsonio.load(os.path.join(logdir, "logs.json"))
+    assert isinstance(logs["params"][0][".kernel.lengthscales"], np.ndarray)        # arrays survive as arrays (json_tricks encoding)
     assert {"loss", "train/rmse", "test/rmse", "train/nlpd", "test/nlpd", "cg/steps", "cg/error", "id"} <= set(results)
     assert {"loss", "elapsed_time", "params", "steps-per-feval", "residual_error-per-feval", "id"} <= set(logs)
     assert results["test/rmse"] < 0.6
@@ -192,7 +243,7 @@ def test_cli_train_and_metric_roundtrip(tmp_path):
 def test_create_model_initialises_inducing_points_on_the_gpu(kernel):
     """create_model -> InducingVariableConfig.init -> cglb_select_inducing: the model's initial Z equals the numpy statement of
     the greedy conditional-variance rule under the initial kernel (unit lengthscales, variance 1; config.py:74-76)."""
-    from cglb_amd.backend.config import greedy_conditional_variance
+    from oracle.cglb_oracle import greedy_conditional_variance
     from cglb_amd.backend.interface import _InitKernel
     be, model, (train, _) = _model(kernel, M=24)
     Z = be.model_parameters(model)[".inducing_variable.Z"]

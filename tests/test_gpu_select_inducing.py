@@ -1,5 +1,5 @@
 """Inducing-point initialisation on the GPU (cglb_select_inducing) against the numpy statement of the same greedy rule
-(cglb_amd.backend.config.greedy_conditional_variance, the mirror of config.py:55-65) and through properties at full size."""
+(oracle.cglb_oracle.greedy_conditional_variance, the restated rule of config.py:55-65) and through properties at full size."""
 import numpy as np
 import pytest
 import torch
@@ -21,7 +21,7 @@ def _kernel_fn(kind, ls, var):
 @pytest.mark.parametrize("kind", ["rbf", "matern32"])
 @pytest.mark.parametrize("N,D,M", [(3000, 3, 100), (700, 8, 64), (1, 2, 1), (50, 1, 50), (257, 16, 9)])
 def test_selection_matches_numpy_greedy(kind, N, D, M):
-    from cglb_amd.backend.config import greedy_conditional_variance
+    from oracle.cglb_oracle import greedy_conditional_variance
     from cglb_amd.hip_context import HipContext
     rng = np.random.default_rng(N + D)
     X = rng.standard_normal((N, D))
