@@ -17,7 +17,8 @@ for f in glob.glob(os.path.join(src, "pass*", "**", "*counter_collection.csv"), 
         if "Start_Timestamp" in r and r["Counter_Name"] == "SQ_WAVE_CYCLES":
             durs[name].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 avg = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in vals.items()}
-want = ["kff_sym_kernel", "kff_sym_combine_kernel", "gemv_u_kernel", "gemv_t_kernel", "precond_z_kernel", "grad_kff_kernel", "select_step_kernel"]
+want = ["kff_sym_kernel", "kff_sym_combine_kernel", "gemv_u_kernel", "gemv_t_kernel", "precond_z_kernel", "grad_kff_kernel", "grad_kff_gram_kernel",
+        "select_step_kernel"]
 hbm = {}
 for k in want:
     if k in avg and "FETCH_SIZE" in avg[k]:
@@ -26,7 +27,7 @@ for k in want:
                   "hbm_bytes_per_launch": 2 * 1024 * f + 1024 * w}
 json.dump({
     "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python3 tools/pmc_run.py  [tools/pmc_collect.sh]",
-    "workload": "N=100000 D=8 M=1024 rbf fp64, MI355X, round 1 (final kernels: XCD-aware item order)",
+    "workload": f"N=100000 D=8 M=1024 rbf fp64, MI355X, {tag} (default precision level)",
     "correction": "MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 64 B per 128-B request on gfx950 for wide coalesced reads -> doubled; WRITE_SIZE exact. Units KB.",
     "note": "The x2 calibration holds for the 16-B/lane streaming reads of gemv_u/gemv_t (2*405 MB = 810 MB vs 819 MB algorithmic). For kff_sym_kernel the reads are scalar-cache refills and row operands, the writes are the partial slabs (Prow/Pcol); treat its figure as an upper estimate. Infinity-Cache hits are included in FETCH_SIZE.",
     "kernels": hbm}, open(f"profiles/{tag}_pmc_hbm_traffic.json", "w"), indent=1)
@@ -36,9 +37,12 @@ for k in want:
         d = {c: v for c, v in avg[k].items() if c.startswith("SQ_") or c.startswith("GRBM")}
         if d:
             sq[k] = d
+            if "SQ_INSTS_VALU_FMA_F64" in d:  # executed fp64 arithmetic of one launch: wave-instructions x 64 lanes, an fma = 2 flop
+                d["executed_flop_per_launch"] = 64.0 * (2.0 * d["SQ_INSTS_VALU_FMA_F64"] + d.get("SQ_INSTS_VALU_ADD_F64", 0.0) + d.get("SQ_INSTS_VALU_MUL_F64", 0.0))
+                d["valu_insts_per_launch"] = d.get("SQ_INSTS_VALU", 0.0)
 json.dump({
     "command": "rocprofv3 --pmc <SQ counters> --kernel-trace --output-format csv -- python3 tools/pmc_run.py (two passes: instruction mix; cycles)  [tools/pmc_collect.sh]",
-    "workload": "N=100000 D=8 M=1024 rbf fp64, MI355X, round 1 (final kernels)",
+    "workload": f"N=100000 D=8 M=1024 rbf fp64, MI355X, {tag} (default precision level)",
     "kernels": sq}, open(f"profiles/{tag}_pmc_sq_counters.json", "w"), indent=1)
 for k, d in hbm.items():
     print(f"{k:28s} fetch_raw {d['FETCH_SIZE_KB_raw']/1e3:9.1f} MB  write {d['WRITE_SIZE_KB_raw']/1e3:8.1f} MB  hbm/launch {d['hbm_bytes_per_launch']/1e6:9.1f} MB")
