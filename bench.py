@@ -319,6 +319,11 @@ def main():
         other_fx = check_against_fixture(N, D, M, kind, secondary["workload_hypers"], None, steps=secondary["cg_steps"], bound=secondary["bound"])
         if other_fx is not None:
             parity["secondary"] = other_fx
+        if "matern32" in secondary:
+            m_fx = check_against_fixture(N, D, M, "matern32", secondary["matern32"]["workload_hypers"], None,
+                                         steps=secondary["matern32"]["cg_steps"], bound=secondary["matern32"]["bound"])
+            if m_fx is not None:
+                parity["matern32"] = m_fx
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
