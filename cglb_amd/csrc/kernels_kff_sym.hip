@@ -12,11 +12,13 @@
 //     per column instead of 18 for sixteen separate wave reductions; the 16 sums land in lanes 0..15 and are
 //     stored with one 128-B store;
 //   * nothing is accumulated with atomics: every (slot, element) of the partial slabs is written by exactly one
-//     wave and the combine kernel adds the valid slots in fixed order, so results are bitwise reproducible.
+//     workgroup and the combine kernel adds the valid slots in fixed order, so results are bitwise reproducible.
 // Slab layout (element type double), n = number of rows of the square block:
 //   Prow[k][li], k < nchunk : row sums of chunk k (valid for k >= first chunk of row block rb(i)); li = compact index of row i among
 //                            the row blocks of this rank (all rows on one GPU), leading dimension prow_ld
-//   Pcol[rb][j], rb < nrb  : column sums produced by row block rb (valid for rb < rb(j))
+//   Pcol[g][j], g < ceil(nrb/4) : column sums produced by the GROUP of row blocks 4g .. 4g+3 of this rank (one workgroup: its four
+//                            waves stage their column sums in LDS and the workgroup stores their fixed-order sum); valid for the
+//                            groups that hold a block left of rb(j); blocks at or right of rb(j) contribute exact zeros
 // The diagonal 64R x 64R blocks are evaluated in full and contribute row sums only.
 //
 // Folded column norm (RBF, unclamped range): kappa_ij = 2^(a_i + x_i.x_j) * w_j with w_j = 2^(a_j), so the per-pair add of
@@ -30,25 +32,15 @@
 #define SYM_BATCH 16
 typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane side by side: v_pk_fma_f32 (fp32 path)
 
+#define SYM_CHUNK_MAX 1024  // column chunk of a work item: at most this many columns (their sums are staged in LDS)
+
+// One work item: rows of block `rb` against the columns of chunk `k` that lie at or right of the block's first row.  Row sums go to
+// Prow; the column sums (transposed use of the kernel values) go to `cs`, this wave's LDS array indexed by column - k * chunk.
 template <typename T, int KIND, int DP, int R, bool CLAMP, int PREC>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
-                                                      const T* __restrict__ pw, const T* __restrict__ wcol,
-                                                      int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items, int nitems,
-                                                      int rb_stride, int64_t prow_ld, T* __restrict__ Prow, T* __restrict__ Pcol,
-                                                      const double* __restrict__ exp_tab) {
-    __shared__ double tab[CGLB_TAB_SIZE];
-    load_exp_table(tab, exp_tab);  // before the early exit below: every thread reaches the barrier inside
+__device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p, const T* __restrict__ pc,
+                                             int64_t row0, int64_t n, int64_t chunk, int64_t rb, int64_t k, int64_t cslot, int64_t prow_ld,
+                                             T* __restrict__ Prow, T* __restrict__ cs, const double* __restrict__ tab, int lane) {
     constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP;
-    const T* __restrict__ pc = FOLD ? pw : p;  // column-side operand
-    const int lane = threadIdx.x & 63;
-    // wave-uniform work item: readfirstlane makes that visible to the compiler, so everything derived from it
-    // (column indices, operand addresses) lives in SGPRs and the column operands are fetched with scalar loads
-    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (item >= nitems) return;  // whole wave exits together
-    const int2 it = items[item];
-    if (__builtin_amdgcn_readfirstlane(it.x) < 0) return;  // padding entry of the XCD-aware item order
-    const int64_t rb = __builtin_amdgcn_readfirstlane(it.x), k = __builtin_amdgcn_readfirstlane(it.y);
-    const int64_t cslot = rb / rb_stride;  // compact Pcol slot: with a cyclic rank distribution only every rb_stride-th block is here
     constexpr int RBROWS = 64 * R;
     const int64_t rbase = rb * RBROWS;
     // fp32: rows in pairs, so that the Gram chain and the two accumulations run as v_pk_fma_f32 (4.8 nominal cycles per pair of
@@ -194,7 +186,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(
             T v = t[0];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (lane < SYM_BATCH) Pcol[cslot * n + jb + lane] = FOLD ? v * wcol[row0 + jb + lane] : v;
+            if (lane < SYM_BATCH) cs[jb - k * chunk + lane] = v;
         }
     }
     if (PACKED) {  // the packed row sums continue unpacked in the tail / are stored below
@@ -224,7 +216,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(
         }
         if (jc >= sym_from) {
             const T v = wave_sum(tj);
-            if (lane == 0) Pcol[cslot * n + jc] = FOLD ? v * wcol[j] : v;
+            if (lane == 0) cs[jc - k * chunk] = v;
         }
     }
 #pragma unroll
@@ -234,7 +226,47 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(
     }
 }
 
-// out[i] = var * ( sum_s plain[s][i] + sum_{k >= k0(i)} Prow[k][i] + sum_{rb < rb(i)} Pcol[rb][i] ) + noise * pdiag[i]
+// A workgroup = 4 waves = 4 consecutive row blocks of this rank against ONE column chunk (`groups[blockIdx.x]` = (group slot, chunk);
+// `items[4 * blockIdx.x + wave]` = (row block or -1, chunk)).  Each wave stages the column sums of its item in LDS; after a barrier
+// the workgroup adds the four arrays in fixed order and stores ONE column-sum vector per (group, chunk): a quarter of the slab
+// elements, writes and combine-kernel reads of one vector per (row block, chunk).
+template <typename T, int KIND, int DP, int R, bool CLAMP, int PREC>
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
+                                                      const T* __restrict__ pw, const T* __restrict__ wcol,
+                                                      int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items,
+                                                      const int2* __restrict__ groups, int rb_stride, int64_t prow_ld, T* __restrict__ Prow,
+                                                      T* __restrict__ Pcol, const double* __restrict__ exp_tab) {
+    __shared__ double tab[CGLB_TAB_SIZE];
+    __shared__ T csum[4 * SYM_CHUNK_MAX];
+    load_exp_table(tab, exp_tab);  // before the early exit below: every thread reaches the barrier inside
+    constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP;
+    const T* __restrict__ pc = FOLD ? pw : p;  // column-side operand
+    const int lane = threadIdx.x & 63;
+    const int2 grp = groups[blockIdx.x];
+    if (__builtin_amdgcn_readfirstlane(grp.x) < 0) return;  // padding workgroup of the XCD-aware order: the whole block leaves together
+    // wave-uniform work item: readfirstlane makes that visible to the compiler, so everything derived from it
+    // (column indices, operand addresses) lives in SGPRs and the column operands are fetched with scalar loads
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int2 it = items[blockIdx.x * 4 + wave];
+    T* __restrict__ cs = csum + wave * SYM_CHUNK_MAX;
+    for (int64_t cidx = lane; cidx < chunk; cidx += 64) cs[cidx] = T(0);  // columns this item does not reach contribute nothing
+    if (__builtin_amdgcn_readfirstlane(it.x) >= 0) {
+        const int64_t rb = __builtin_amdgcn_readfirstlane(it.x), k = __builtin_amdgcn_readfirstlane(it.y);
+        const int64_t cslot = rb / rb_stride;  // compact slot: with a cyclic rank distribution only every rb_stride-th block is here
+        kff_sym_item<T, KIND, DP, R, CLAMP, PREC>(Xs, xa, p, pc, row0, n, chunk, rb, k, cslot, prow_ld, Prow, cs, tab, lane);
+    }
+    __syncthreads();
+    const int64_t gslot = __builtin_amdgcn_readfirstlane(grp.x), k = __builtin_amdgcn_readfirstlane(grp.y);
+    for (int64_t cidx = threadIdx.x; cidx < chunk; cidx += 256) {
+        const int64_t j = k * chunk + cidx;
+        if (j < n) {
+            const T sum = (csum[cidx] + csum[SYM_CHUNK_MAX + cidx]) + (csum[2 * SYM_CHUNK_MAX + cidx] + csum[3 * SYM_CHUNK_MAX + cidx]);
+            Pcol[gslot * n + j] = FOLD ? sum * wcol[row0 + j] : sum;
+        }
+    }
+}
+
+// out[i] = var * ( sum_s plain[s][i] + sum_{k >= k0(i)} Prow[k][i] + sum_{groups g of row blocks < rb(i)} Pcol[g][i] ) + noise * pdiag[i]
 // With a cyclic distribution (world > 1) only the row blocks rb == rank (mod world) were processed here: row sums exist for
 // the rows of those blocks, column sums come from those blocks only, and only rank 0 adds the noise term (pdiag == null elsewhere).
 // Block = 64 elements x 4 slot groups: wave g adds the slots g, g+4, g+8, ... of each of the three slab lists (8 loads in flight
@@ -266,7 +298,9 @@ __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restric
             for (int u = 0; k < nchunk; k += 4, ++u) a[u] += Prow[k * prow_ld + li];
         }
         {
-            const int64_t ns = rbi > rank ? (rbi - rank + world - 1) / world : 0;  // column-sum slots 0 .. ns-1 are valid for this element
+            // this rank's row blocks before block rbi contributed to column i; they are stored four to a slot (one per workgroup)
+            const int64_t nbefore = rbi > rank ? (rbi - rank + world - 1) / world : 0;
+            const int64_t ns = (nbefore + 3) / 4;
             int64_t c = g;
             for (; c + 28 < ns; c += 32) {
 #pragma unroll
@@ -320,75 +354,83 @@ __global__ __launch_bounds__(256) void finalize_sum_sym_kernel(const double* __r
 }
 
 
-static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, int world, int rank, int* nitems_out, int* nrb_out,
+// Work list of the symmetric kernel.  Unit = a GROUP: 4 consecutive row blocks of this rank (local block index lb = 4g .. 4g+3,
+// global rb = rank + lb * world) against one column chunk k - one workgroup, one wave per row block.  A group exists for chunk k if its
+// first (leftmost) block reaches into the chunk; a block of the group that lies wholly right of the chunk is a -1 entry.
+//   items[4 * b + w] = (rb or -1, k),  groups[b] = (g, k) or (-1, -1) for a padding workgroup.
+static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, int world, int rank, int* nblocks_out, int* nrb_out,
                             int* nchunk_out) {
     const int nrb = (int)((n + rbrows - 1) / rbrows);
     const int nchunk = (int)((n + chunk - 1) / chunk);
     if (c->sym_items && c->sym_n == n && c->sym_rbrows == rbrows && c->sym_chunk == chunk && c->sym_world == world && c->sym_rank == rank &&
         c->sym_order_built == c->sym_order) {
-        *nitems_out = c->sym_nitems; *nrb_out = nrb; *nchunk_out = nchunk;
+        *nblocks_out = c->sym_nitems; *nrb_out = nrb; *nchunk_out = nchunk;
         return CGLB_OK;
     }
-    std::vector<int2> items;
+    const int nlb = rank < nrb ? (nrb - rank + world - 1) / world : 0;  // row blocks of this rank
+    const int ngroups = (nlb + 3) / 4;
+    auto first_chunk = [&](int lb) { return (int)((((int64_t)rank + (int64_t)lb * world) * rbrows) / chunk); };  // chunk holding the block's first row
+    std::vector<int2> sorted;  // (g, k)
     if (c->sym_order == 0) {
-        // row-block major, longest rows first (row block 0 sweeps the most columns)
-        for (int rb = rank; rb < nrb; rb += world) {
-            const int k0 = (int)(((int64_t)rb * rbrows) / chunk);
-            for (int k = k0; k < nchunk; ++k) items.push_back(make_int2(rb, k));
-        }
+        // group major, longest rows first (group 0 sweeps the most columns)
+        for (int g = 0; g < ngroups; ++g)
+            for (int k = first_chunk(4 * g); k < nchunk; ++k) sorted.push_back(make_int2(g, k));
     } else {
         // XCD-aware order.  Workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8), each with its own 4-MB L2, and the
-        // streamed side of an item is its column chunk (chunk * (DP + 2) operands, 80 KB at 1024 columns).  Items are sorted by
+        // streamed side of a workgroup is its column chunk (chunk * (DP + 2) operands, 80 KB at 1024 columns).  Groups are sorted by
         // column chunk and the sorted list is cut into 8 contiguous ranges of equal length, one per XCD: an XCD then only ever
         // streams its own ~1/8 of the columns (L2-resident), instead of every XCD sweeping all of X through the Infinity Cache.
-        std::vector<int2> sorted;
-        for (int k = 0; k < nchunk; ++k) {
-            const int64_t last_row = (int64_t)(k + 1) * chunk - 1 < n - 1 ? (int64_t)(k + 1) * chunk - 1 : n - 1;
-            const int rb_hi = (int)(last_row / rbrows);  // row blocks whose first row is <= the last column of the chunk
-            for (int rb = rank; rb <= rb_hi && rb < nrb; rb += world)
-                if ((int)(((int64_t)rb * rbrows) / chunk) <= k) sorted.push_back(make_int2(rb, k));
-        }
-        const int XCDS = 8, WG = 4;
-        const size_t T = sorted.size();
-        size_t per_xcd = (T + XCDS - 1) / XCDS;
-        per_xcd = (per_xcd + WG - 1) / WG * WG;  // whole workgroups
-        const size_t groups = per_xcd / WG;      // workgroups per XCD
-        items.assign(per_xcd * XCDS, make_int2(-1, -1));
-        // inside an XCD's range (a dozen column chunks, ~1 MB of streamed operands that stay in its L2) go row block by row block,
-        // so that the 20 KB of row operands of a block are fetched once per XCD rather than once per item
+        for (int k = 0; k < nchunk; ++k)
+            for (int g = 0; g < ngroups; ++g)
+                if (first_chunk(4 * g) <= k) sorted.push_back(make_int2(g, k));
+    }
+    const size_t T = sorted.size();
+    std::vector<int2> order;  // workgroup b -> (g, k) or (-1, -1)
+    if (c->sym_order == 0) {
+        order = sorted;
+    } else {
+        const int XCDS = 8;
+        const size_t per_xcd = (T + XCDS - 1) / XCDS;  // workgroups per XCD
+        order.assign(per_xcd * XCDS, make_int2(-1, -1));
+        // inside an XCD's range (a dozen column chunks, ~1 MB of streamed operands that stay in its L2) go group by group,
+        // so that the row operands of a group are fetched once per XCD rather than once per workgroup
         for (size_t x = 0; x < (size_t)XCDS; ++x) {
             const size_t lo = x * per_xcd < T ? x * per_xcd : T, hi = (x + 1) * per_xcd < T ? (x + 1) * per_xcd : T;
             std::stable_sort(sorted.begin() + lo, sorted.begin() + hi, [](const int2& a, const int2& b) { return a.x < b.x; });
+            for (size_t q = lo; q < hi; ++q) order[(q - lo) * XCDS + x] = sorted[q];  // workgroup index that lands on XCD x
         }
-        for (size_t x = 0; x < (size_t)XCDS; ++x)
-            for (size_t sgrp = 0; sgrp < groups; ++sgrp)
-                for (size_t w = 0; w < (size_t)WG; ++w) {
-                    const size_t src = x * per_xcd + sgrp * WG + w;
-                    const size_t b = sgrp * XCDS + x;  // workgroup index that lands on XCD x
-                    if (src < T) items[b * WG + w] = sorted[src];
-                }
     }
-    // evaluated kernel pairs of one launch (cglb_get_stat "k1_pairs_per_launch"): rows of the block x columns at or right of its first row
-    double pairs = 0.0;
-    for (const int2& it : items) {
-        if (it.x < 0) continue;
-        const int64_t rbase = (int64_t)it.x * rbrows;
-        const int64_t rows = (n - rbase < rbrows) ? n - rbase : rbrows;
-        int64_t j0 = (int64_t)it.y * chunk, j1 = ((int64_t)it.y + 1) * chunk;
-        if (j0 < rbase) j0 = rbase;
-        if (j1 > n) j1 = n;
-        if (j1 > j0) pairs += (double)rows * (double)(j1 - j0);
+    std::vector<int2> items(order.size() * 4, make_int2(-1, -1));
+    double pairs = 0.0;  // evaluated kernel pairs of one launch (cglb_get_stat "k1_pairs_per_launch")
+    for (size_t b = 0; b < order.size(); ++b) {
+        const int g = order[b].x, k = order[b].y;
+        if (g < 0) continue;
+        for (int w = 0; w < 4; ++w) {
+            const int lb = 4 * g + w;
+            items[4 * b + w] = make_int2(-1, k);
+            if (lb >= nlb || first_chunk(lb) > k) continue;
+            const int rb = rank + lb * world;
+            items[4 * b + w] = make_int2(rb, k);
+            const int64_t rbase = (int64_t)rb * rbrows;
+            const int64_t rows = (n - rbase < rbrows) ? n - rbase : rbrows;
+            int64_t j0 = (int64_t)k * chunk, j1 = ((int64_t)k + 1) * chunk;
+            if (j0 < rbase) j0 = rbase;
+            if (j1 > n) j1 = n;
+            if (j1 > j0) pairs += (double)rows * (double)(j1 - j0);
+        }
     }
-    c->sym_pairs = (rank < nrb) ? pairs : 0.0;
+    c->sym_pairs = pairs;
     if (c->sym_items) HIP_CHECK(c, hipFree(c->sym_items));
     c->sym_items = nullptr;
-    if (items.empty()) items.push_back(make_int2(0, 0));  // keep the allocation non-empty; nitems stays 0
-    HIP_CHECK(c, hipMalloc(&c->sym_items, items.size() * sizeof(int2)));
+    if (order.empty()) { order.push_back(make_int2(-1, -1)); items.assign(4, make_int2(-1, -1)); }  // keep the allocation non-empty
+    // one allocation: the items first, the groups behind them
+    HIP_CHECK(c, hipMalloc(&c->sym_items, (items.size() + order.size()) * sizeof(int2)));
     HIP_CHECK(c, hipMemcpyAsync(c->sym_items, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(c, hipMemcpyAsync((int2*)c->sym_items + items.size(), order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(c, hipStreamSynchronize(c->stream));
     c->sym_n = n; c->sym_rbrows = rbrows; c->sym_chunk = chunk; c->sym_world = world; c->sym_rank = rank; c->sym_order_built = c->sym_order;
-    c->sym_nitems = (rank < nrb) ? (int)items.size() : 0;
-    *nitems_out = c->sym_nitems; *nrb_out = nrb; *nchunk_out = nchunk;
+    c->sym_nitems = T > 0 ? (int)order.size() : 0;  // number of workgroups
+    *nblocks_out = c->sym_nitems; *nrb_out = nrb; *nchunk_out = nchunk;
     return CGLB_OK;
 }
 
@@ -412,15 +454,17 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     }
     if (c->sym_chunk_opt > 0) chunk = c->sym_chunk_opt;
     chunk = (chunk + SYM_BATCH - 1) / SYM_BATCH * SYM_BATCH;
-    int nitems = 0, nrb = 0, nchunk = 0;
-    CGLB_TRY(ensure_sym_items(c, n, RBROWS, chunk, world, rank, &nitems, &nrb, &nchunk));
-    const int ncslot = (nrb + world - 1) / world;
+    if (chunk > SYM_CHUNK_MAX) chunk = SYM_CHUNK_MAX;  // the column sums of a chunk are staged in LDS
+    int nblocks = 0, nrb = 0, nchunk = 0;
+    CGLB_TRY(ensure_sym_items(c, n, RBROWS, chunk, world, rank, &nblocks, &nrb, &nchunk));
+    const int ncslot = (nrb + world - 1) / world;      // row blocks of a rank (upper bound): row-sum slab rows
+    const int ngslot = (ncslot + 3) / 4;               // groups of four of them: column-sum slabs
     // off-diagonal column ranges of the row shard ([0,r0) and [r1,N)) go through the plain kernel
     const int64_t nleft = cyclic ? 0 : c->r0, nright = cyclic ? 0 : c->N - c->r1;
     int64_t plain_slots_max = 0;
     if (nleft > 0 || nright > 0) plain_slots_max = 2 * 512;
     const int64_t prow_ld = (int64_t)ncslot * RBROWS;  // compact rows of this rank's row blocks
-    const size_t need = (((size_t)plain_slots_max + ncslot) * n + (size_t)nchunk * prow_ld) * sizeof(T);
+    const size_t need = (((size_t)plain_slots_max + ngslot) * n + (size_t)nchunk * prow_ld) * sizeof(T);
     if (need > c->kpart_cap) {
         if (c->kpart) HIP_CHECK(c, hipFree(c->kpart));
         c->kpart = nullptr;
@@ -447,7 +491,9 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     }
     T* Prow = plain + nplain * n;
     T* Pcol = Prow + (int64_t)nchunk * prow_ld;
-    const int grid = (nitems + 3) / 4;
+    const int grid = nblocks;
+    const int2* items_dev = (const int2*)c->sym_items;
+    const int2* groups_dev = items_dev + (size_t)4 * (nblocks > 0 ? nblocks : 1);
     if (grid > 0) {
         if (!c->exp_clamp && KIND == CGLB_RBF) {  // folded column norm: pre-weight the operand over the columns of this block
             // (skipped when the update_p kernel that produced exactly this vector has already written the weighted copy)
@@ -478,11 +524,11 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
         CGLB_DISPATCH_PREC(c, {
             if (c->exp_clamp)
                 hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true, PREC>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah,
-                                   p_full, (const T*)nullptr, (const T*)nullptr, row0, n, chunk, (const int2*)c->sym_items, nitems, world, prow_ld, Prow,
+                                   p_full, (const T*)nullptr, (const T*)nullptr, row0, n, chunk, items_dev, groups_dev, world, prow_ld, Prow,
                                    Pcol, (const double*)c->exp_tab);
             else
                 hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false, PREC>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah,
-                                   p_full, (const T*)c->pwh, (const T*)c->wh, row0, n, chunk, (const int2*)c->sym_items, nitems, world, prow_ld, Prow,
+                                   p_full, (const T*)c->pwh, (const T*)c->wh, row0, n, chunk, items_dev, groups_dev, world, prow_ld, Prow,
                                    Pcol, (const double*)c->exp_tab);
         });
         CGLB_LAUNCH_CHECK(c);

@@ -32,7 +32,8 @@ for kind in ("rbf", "matern32"):
     np.save(os.path.join(os.environ["OUTDIR"], out["lib"] + "." + kind + ".npy"), Ap)
     ms = [ctx.time_kernel(3, 10) for _ in range(3)]
     mg = [ctx.time_kernel(2, 5) for _ in range(2)]
-    out[kind] = {"k1_ms": min(ms), "k1_ms_all": ms, "grad_ms": min(mg)}
+    mv = [ctx.time_kernel(0, 10) for _ in range(3)]
+    out[kind] = {"k1_ms": min(ms), "k1_ms_all": ms, "grad_ms": min(mg), "matvec_ms": min(mv)}
     ctx.close()
 print("RESULT " + json.dumps(out))
 """
@@ -54,8 +55,8 @@ def main():
                 continue
             r = json.loads(line[0][7:])
             results.setdefault(r["lib"], []).append(r)
-            print(f"round {rnd} {r['lib']:28s} rbf K1 {r['rbf']['k1_ms']:.3f} ms grad {r['rbf']['grad_ms']:.3f} | "
-                  f"matern32 K1 {r['matern32']['k1_ms']:.3f} ms grad {r['matern32']['grad_ms']:.3f}", flush=True)
+            print(f"round {rnd} {r['lib']:28s} rbf K1 {r['rbf']['k1_ms']:.3f} ms mat-vec {r['rbf']['matvec_ms']:.3f} grad {r['rbf']['grad_ms']:.3f} | "
+                  f"matern32 K1 {r['matern32']['k1_ms']:.3f} ms mat-vec {r['matern32']['matvec_ms']:.3f} grad {r['matern32']['grad_ms']:.3f}", flush=True)
     # accuracy: against the first library and against the blocked C oracle on a row sample
     import numpy as np
     import torch
