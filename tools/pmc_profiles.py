@@ -1,6 +1,6 @@
 """Developer tool: turn the rocprofv3 --pmc passes collected by tools/pmc_collect.sh into the two summaries under profiles/.
 
-usage: python tools/pmc_profiles.py gpurun_out/pmc_final r01
+usage: python tools/pmc_profiles.py gpurun_out/r02_pmc r02
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 64 B per
 128-B request for wide coalesced reads, so it is doubled (calibrated here on gemv_u / gemv_t, whose algorithmic read is exactly
 the 819 MB panel); WRITE_SIZE is taken as is.
