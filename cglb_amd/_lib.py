@@ -48,6 +48,7 @@ SIGNATURES = {
     "cglb_pcg_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int, c_int, POINTER(c_int), POINTER(c_double)]),
     "cglb_objective_and_grad": (c_int, [c_void_p, c_void_p, c_int, c_double, c_int, c_int, POINTER(c_double), POINTER(c_double),
                                         POINTER(c_int), POINTER(c_double)]),
+    "cglb_objective_grad_v": (c_int, [c_void_p, c_void_p]),
     "cglb_shard_obj_phase1": (c_int, [c_void_p, c_void_p, c_void_p]),
     "cglb_shard_obj_phase2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cglb_shard_obj_phase3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -28,13 +28,18 @@ __all__ = ["create_kernel", "create_model", "optimize", "save", "load", "metrics
 Tensor = torch.Tensor
 Data = Tuple[np.ndarray, np.ndarray]
 
-_STATE = {"dtype": torch.float64, "logdir": None}
+_STATE = {"dtype": torch.float64, "logdir": None, "config_semantics": "torch"}
 
 
-def configure_backend(logdir: Optional[str] = None, keops: Optional[bool] = None, **kwargs):
-    """interface.py:66-88.  `keops` is accepted and ignored: the implicit K_ff mat-vec is always the HIP kernel."""
+def configure_backend(logdir: Optional[str] = None, keops: Optional[bool] = None, config_semantics: str = "torch", **kwargs):
+    """interface.py:66-88.  `keops` is accepted and ignored: the implicit K_ff mat-vec is always the HIP kernel.
+    config_semantics: "torch" (default) mirrors pytorch/interface.py:315-323, which ignores `max_error` / `joint_optimization` / `vzero`
+    of CGLBConfig; "tf" consumes them like the TF twin's create_model (tensorflow/interface.py:244-258, models.py:31-51,161-164)."""
     assert logdir is not None
+    if config_semantics not in ("torch", "tf"):
+        raise ValueError("config_semantics must be 'torch' or 'tf'")
     _STATE["logdir"] = logdir
+    _STATE["config_semantics"] = config_semantics
     if not torch.cuda.is_available():
         raise RuntimeError("the hip backend needs an MI355X (HIP device); there is no CPU fallback")
 
@@ -179,9 +184,13 @@ def _likelihood_and_kernel_for_sgpr(model_cfg: SGPRConfig, data: Data):
 @create_model.register
 def _create_model_cglb(model_cfg: CGLBConfig, data: Data):
     """interface.py:315-323.  Like the reference's torch path, max_error / joint_optimization / vzero of the config
-    are not consumed here: the objective uses ConjugateGradient() defaults."""
+    are not consumed here (the objective uses ConjugateGradient() defaults) unless the backend was configured with
+    config_semantics="tf"."""
     likelihood, kernel = _likelihood_and_kernel_for_sgpr(model_cfg, data)
-    return CGLB((np.asarray(data[0]), np.asarray(data[1]).reshape(-1)), likelihood, kernel, dtype=_STATE["dtype"])
+    extra = {}
+    if _STATE["config_semantics"] == "tf":  # the TF twin's create_model hands these to the model (tensorflow/interface.py:244-258)
+        extra = dict(max_error=model_cfg.max_error, joint_optimization=model_cfg.joint_optimization, vzero=model_cfg.vzero)
+    return CGLB((np.asarray(data[0]), np.asarray(data[1]).reshape(-1)), likelihood, kernel, dtype=_STATE["dtype"], **extra)
 
 
 @optimize.register

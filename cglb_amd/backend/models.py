@@ -145,12 +145,20 @@ class CGLB(SGPR):
     """models.py:54-87: SGPR + the persistent warm-start vector v_vec (zeros[N,1], no grad) and cg_stats."""
 
     def __init__(self, data: Data, likelihood: GaussianLikelihood, kernel: InducingPointKernel, dtype: torch.dtype = torch.float64,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, max_error: Optional[float] = None, joint_optimization: bool = False,
+                 vzero: bool = False):
+        """The last three arguments are the TF twin's (tensorflow/models.py:31-51): the torch reference never passes them
+        (pytorch/interface.py:315-323) and neither does `create_model` unless `configure_backend(config_semantics="tf")`.
+        `max_error` becomes the default tolerance of `LowerBoundCG`; `joint_optimization` (without `vzero`) makes `v_vec` a trainable
+        parameter and skips CG; `vzero` keeps v = 0 and skips CG (tensorflow/models.py:161-164)."""
         super().__init__(data, likelihood, kernel)
         self.dtype = dtype
+        self.max_error, self.joint_optimization, self.vzero = max_error, bool(joint_optimization), bool(vzero)
         kind = kernel.base_kernel.base_kernel.kind
         self.hip = HipContext(self.train_inputs[0], self.train_targets, kernel.inducing_points.shape[0], kind, dtype=dtype, device=device)
-        self._v_vec = self._build_v_vec()
+        v0 = self._build_v_vec()
+        # v0 trainable only under joint optimisation (tensorflow/models.py:47-48); otherwise a plain buffer without grad (models.py:59-68)
+        self._v_vec = nn.Parameter(v0) if (self.joint_optimization and not self.vzero) else v0
         self._hyper_token = None
 
     def check_same_data(self, data: Data) -> None:
@@ -220,13 +228,15 @@ class _BoundFunction(torch.autograd.Function):
     """bound(lengthscales, variance, noise, mean, Z) with the analytic gradient from the GPU (row G of SURVEY 8a)."""
 
     @staticmethod
-    def forward(ctx, owner, ls, var, noise, mean, Z):
+    def forward(ctx, owner, ls, var, noise, mean, Z, v_param=None):
         model = owner.model
         hip = model.hip
         hip.set_hypers(ls.detach().cpu().numpy(), float(var), float(noise), float(mean), Z.detach().cpu(), get_cholesky_jitter())
         need_grad = any(ctx.needs_input_grad[1:])
-        v = model.v_vec.reshape(-1)
+        v = model.v_vec.detach().reshape(-1)
         run_cg = not (owner._use_cache and owner.cached_v_vec)          # models.py:263
+        if model.joint_optimization or model.vzero:                     # tensorflow/models.py:161-164: v0 is used as it stands
+            run_cg = False
         cg = owner.cg_opt
         if run_cg and type(cg) is not ConjugateGradient:
             # foreign plug-in solver through the seam (models.py:266-271): cg_opt(A, b, v, precond)
@@ -245,6 +255,9 @@ class _BoundFunction(torch.autograd.Function):
         owner.last_bounds = Bounds(upper_bound=torch.tensor(-res.upper), lower_bound=torch.tensor(-res.lower))  # models.py:286
         model.last_bound = float(res.bound)  # value of the most recent evaluation (diagnostics / tests)
         ctx.grads = res.grad
+        ctx.grad_v = None
+        if v_param is not None and ctx.needs_input_grad[6]:            # joint optimisation: d bound / d v = K w - r, one more mat-vec
+            ctx.grad_v = hip.objective_grad_v().reshape(v_param.shape)
         return torch.tensor(res.bound, dtype=torch.float64)
 
     @staticmethod
@@ -253,8 +266,9 @@ class _BoundFunction(torch.autograd.Function):
         if g is None:
             raise RuntimeError("gradient was not requested in forward")
         gout = gout.to(torch.float64)
+        gv = None if ctx.grad_v is None else gout.to(ctx.grad_v.device) * ctx.grad_v
         return (None, gout * torch.from_numpy(g["lengthscales"]), gout * g["variance"], gout * g["noise"], gout * g["mean"],
-                gout * torch.from_numpy(g["Z"]))
+                gout * torch.from_numpy(g["Z"]), gv)
 
 
 class LowerBoundCG(nn.Module):
@@ -266,7 +280,10 @@ class LowerBoundCG(nn.Module):
             raise ValueError(f"CGLB model expected in the constructor of the {self.__class__}")  # models.py:112-113
         super().__init__()
         object.__setattr__(self, "model", model)  # not a sub-module: parameters stay owned by the model
-        self.cg_opt = ConjugateGradient() if cg_opt is None else cg_opt
+        if cg_opt is None:  # the model carries a tolerance only under the TF twin's config semantics (tensorflow/models.py:36-51)
+            tol = getattr(model, "max_error", None)
+            cg_opt = ConjugateGradient() if tol is None else ConjugateGradient(max_error=float(tol))
+        self.cg_opt = cg_opt
         self._cached_v_vec = cached_v_vec_initial
         self._use_cache = use_cache
         self.last_bounds: Optional[Bounds] = None
@@ -302,7 +319,8 @@ class LowerBoundCG(nn.Module):
         if data is not None:
             self.model.check_same_data(data)
         ls, var, noise, mean, Z = self.model.hyper_tensors()
-        return _BoundFunction.apply(self, ls, var, noise, mean, Z)
+        v_param = self.model.v_vec if isinstance(self.model.v_vec, nn.Parameter) else None
+        return _BoundFunction.apply(self, ls, var, noise, mean, Z, v_param)
 
 
 class PredictCG(LowerBoundCG):

@@ -25,7 +25,8 @@ class _FlatView:
         self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(int)
 
     def gather(self, tensors: Iterable[torch.Tensor]) -> torch.Tensor:
-        return torch.cat([t.reshape(-1) for t in tensors])
+        # parameters may live on different devices (the hypers on the host, a trainable v on the GPU): pack on the host
+        return torch.cat([t.detach().reshape(-1).to("cpu", torch.float64) for t in tensors])
 
     def split(self, flat: torch.Tensor) -> List[torch.Tensor]:
         return [flat[a:b].to(t.dtype).reshape(s) for a, b, s, t in zip(self.offsets[:-1], self.offsets[1:], self.shapes, self.tensors)]
@@ -34,7 +35,7 @@ class _FlatView:
         if len(values) != len(self.tensors):
             raise ValueError("to_tensors and values should have same length")
         for dst, src in zip(self.tensors, values):
-            dst.data = src
+            dst.data = src.to(dst.device)
 
 
 class Scipy:

@@ -581,6 +581,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
 }
 
 int cglb_set_data(cglb_ctx* c, const void* X, const void* y) {
+    if (c) c->obj_valid = false;
     if (!c || !X || !y) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     HIP_CHECK(c, hipSetDevice(c->device));
     const size_t nx = (size_t)c->N * c->D;
@@ -607,6 +608,7 @@ int cglb_set_data(cglb_ctx* c, const void* X, const void* y) {
 }
 
 int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, double noise, double mean, const void* Z, double jitter) {
+    if (c) c->obj_valid = false;
     if (!c || !lengthscales || !Z) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     if (!c->have_data) return cglb_fail(c, CGLB_ERR_STATE, "set_data must precede set_hypers");
     if (!(variance > 0) || !(noise > 0) || !(jitter >= 0) || !std::isfinite(mean)) return cglb_fail(c, CGLB_ERR_BAD_ARG, "variance/noise must be positive, jitter >= 0");
@@ -713,6 +715,7 @@ int cglb_cross_matvec(cglb_ctx* c, const void* xnew, int64_t n_new, const void* 
 }
 
 int cglb_precond_apply(cglb_ctx* c, const void* r, void* z, double* rz) {
+    if (c) c->obj_valid = false;
     if (!c || !r || !z) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     CGLB_TRY(require_single(c));
     CGLB_TRY(require_terms(c));
@@ -729,6 +732,7 @@ int cglb_shard_precond_u(cglb_ctx* c, const void* r_local, void* u_partial) {
     return precond_u_any(c, r_local, u_partial);
 }
 int cglb_shard_precond_z(cglb_ctx* c, const void* r_local, const void* u, void* z_local, void* rz_partial) {
+    if (c) c->obj_valid = false;
     if (!c || !r_local || !u || !z_local) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;  // rz_partial may be NULL
     CGLB_TRY(require_terms(c));
     HIP_CHECK(c, hipSetDevice(c->device));
@@ -737,6 +741,7 @@ int cglb_shard_precond_z(cglb_ctx* c, const void* r_local, const void* u, void* 
 }
 
 int cglb_shard_precond_z_seg(cglb_ctx* c, const void* r_local, const void* u, void* z_slot, int64_t per) {
+    if (c) c->obj_valid = false;
     if (!c || !r_local || !u || !z_slot || per < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
     if (per < c->nloc) return cglb_fail(c, CGLB_ERR_BAD_ARG, "precond_z_seg: slice shorter than the local rows");
     if (c->precond_mode != 0) return cglb_fail(c, CGLB_ERR_STATE, "precond_z_seg needs the stored-panel preconditioner (precond_mode 0)");
@@ -813,6 +818,7 @@ int cglb_vec_axpy(cglb_ctx* c, int64_t n, double alpha, const void* x, void* y) 
     return launch_axpy(c, y, alpha, x, n);
 }
 int cglb_shard_obj_phase1_kv(cglb_ctx* c, const void* Kv_local, void* u_partial) {
+    if (c) c->obj_valid = false;
     if (!c || !Kv_local || !u_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     CGLB_TRY(require_terms(c));
     HIP_CHECK(c, hipSetDevice(c->device));
@@ -836,6 +842,7 @@ int cglb_shard_obj_phase3_cyclic(cglb_ctx* c, const void* v_full, const void* u_
 }
 
 int cglb_pcg_solve(cglb_ctx* c, const void* b, void* v_inout, double max_error, int max_cg_iter, int restart_cg_iter, int* steps, double* half_rz) {
+    if (c) c->obj_valid = false;
     if (!c || !b || !v_inout) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     CGLB_TRY(require_single(c));
     CGLB_TRY(require_terms(c));
@@ -844,6 +851,7 @@ int cglb_pcg_solve(cglb_ctx* c, const void* b, void* v_inout, double max_error, 
 }
 
 int cglb_shard_obj_phase1(cglb_ctx* c, const void* v_full, void* u_partial) {
+    if (c) c->obj_valid = false;
     if (!c || !v_full || !u_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     CGLB_TRY(require_terms(c));
     HIP_CHECK(c, hipSetDevice(c->device));
@@ -871,6 +879,7 @@ int cglb_shard_obj_finish(cglb_ctx* c, const void* sc, double* out4) {
 int cglb_objective_and_grad(cglb_ctx* c, void* v_inout, int run_cg, double max_error, int max_cg_iter, int restart_cg_iter, double* out4,
                             double* grad, int* steps, double* half_rz) {
     if (!c || !v_inout || !out4) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    c->obj_valid = false;
     CGLB_TRY(require_single(c));
     CGLB_TRY(cglb_setup(c));                                                        // models.py:155
     if (steps) *steps = 0;
@@ -887,7 +896,20 @@ int cglb_objective_and_grad(cglb_ctx* c, void* v_inout, int run_cg, double max_e
         CGLB_DISPATCH_T(c->dtype, CGLB_TRY(obj_phase3_impl<T>(c, v_inout, sc, c->w_u, c->gradbuf)));
         HIP_CHECK(c, hipMemcpyAsync(grad, c->gradbuf, (size_t)CGLB_GRAD_LEN(c->D, c->M) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    return obj_finish(c, sc, out4);
+    CGLB_TRY(obj_finish(c, sc, out4));
+    c->obj_valid = true;  // r = e - K v and w = P r of this evaluation stay in the work vectors (cglb_objective_grad_v)
+    return CGLB_OK;
+}
+
+int cglb_objective_grad_v(cglb_ctx* c, void* gv_out) {
+    if (!c || !gv_out) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_single(c));
+    if (!c->obj_valid) return cglb_fail(c, CGLB_ERR_STATE, "cglb_objective_grad_v must directly follow cglb_objective_and_grad");
+    HIP_CHECK(c, hipSetDevice(c->device));
+    // bound = -upper + ..., upper = v^T e - v^T K v / 2 + r^T P r / 2, r = e - K v (K incl. the noise term)  =>
+    // d bound / d v = -(e - K v) + K P r = K w - r
+    CGLB_TRY(launch_kff_matvec(c, c->w_z, c->w_Ap, nullptr));
+    return launch_residual(c, gv_out, c->w_Ap, c->w_r);
 }
 
 // ---- inducing-point initialisation (config.py:55-65; kernels_select.hip) -------------------------------------------
@@ -926,6 +948,7 @@ int cglb_select_inducing(cglb_ctx* c, const double* lengthscales, double varianc
 }
 
 int cglb_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var) {
+    if (c) c->obj_valid = false;
     if (!c || !v_full || !xnew || !f_mean || !f_var || n_new < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
     CGLB_TRY(require_single(c));
     CGLB_TRY(require_terms(c));
@@ -1005,6 +1028,7 @@ int cglb_get_stat(cglb_ctx* c, const char* name, double* value) {
 }
 
 int cglb_time_kernel(cglb_ctx* c, int which, int reps, double* ms_avg) {
+    if (c) c->obj_valid = false;
     if (!c || !ms_avg || reps <= 0) return CGLB_ERR_BAD_ARG;
     if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede timing");
     if (which != 0 && which != 3 && which != 4) CGLB_TRY(require_terms(c));

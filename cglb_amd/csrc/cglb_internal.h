@@ -23,6 +23,7 @@ struct cglb_ctx {
     rocblas_handle blas = nullptr;
     // state flags
     bool have_data = false, have_hypers = false, have_local = false, have_terms = false;
+    bool obj_valid = false;  // w_r / w_z hold r = e - K v and w = P r of the last cglb_objective_and_grad
     // raw data (element type T)
     void *X = nullptr, *y = nullptr, *Z = nullptr;
     double xmean[CGLB_MAX_D] = {0};  // column means of X (centre for the Gram form)

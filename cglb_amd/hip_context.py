@@ -171,6 +171,12 @@ class HipContext:
         _lib.check(rc, self._ctx)
         return ObjectiveResult(out4[0], out4[1], out4[2], out4[3], steps.value, half.value, self.unpack_grad(g) if with_grad else None)
 
+    def objective_grad_v(self) -> torch.Tensor:
+        """d bound / d v at the v of the evaluation just made (TF twin's joint optimisation of v, tensorflow/models.py:161-164)."""
+        out = self.empty(self.N)
+        _lib.check(self.lib.cglb_objective_grad_v(self._ctx, _ptr(out)), self._ctx)
+        return out
+
     def unpack_grad(self, g: np.ndarray) -> dict:
         D, M = self.D, self.M
         return {"lengthscales": g[:D].copy(), "variance": float(g[D]), "noise": float(g[D + 1]), "mean": float(g[D + 2]),

@@ -122,6 +122,11 @@ int cglb_pcg_solve(cglb_ctx* ctx, const void* b /* dev [n] */, void* v_inout /* 
 int cglb_objective_and_grad(cglb_ctx* ctx, void* v_inout, int run_cg, double max_error, int max_cg_iter,
                             int restart_cg_iter, double* out4, double* grad, int* steps, double* half_rz);
 
+/* TF twin only (tensorflow/models.py:36-51,161-164: `joint_optimization` makes v a trainable parameter): gradient of the bound
+ * wrt v at the v of the evaluation just made, d bound / d v = K_sigma (P r) - r with r = e - K_sigma v.  Must directly follow
+ * cglb_objective_and_grad (single shard); one more K_ff mat-vec.  gv_out: dev [n]. */
+int cglb_objective_grad_v(cglb_ctx* ctx, void* gv_out);
+
 /* sharded pieces of the same evaluation (host all-reduces between phases):
  *   phase1: Kv = (K+sI) v (v_full gathered), r = e - Kv, u_partial = A_loc r              -> all-reduce u[m]
  *   phase2: w = P r (local), partial scalars sc[8] and aw_partial = A_loc w               -> all-reduce sc[8], aw[m]

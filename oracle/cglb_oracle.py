@@ -221,6 +221,8 @@ def objective(kind, X, y, hyp: Hypers, v0: np.ndarray, run_cg: bool = True,
                     steps=stats.steps, residual_error=stats.residual_error, v=v)
     if with_grad:
         out.grad = objective_grad(kind, X, hyp, terms, v, w)
+        # TF twin (tensorflow/models.py:161-164, `joint_optimization`): v itself is a variable there; d bound / d v = K w - r
+        out.grad["v"] = cov @ w - r
     return out
 
 

@@ -249,3 +249,54 @@ def test_create_model_initialises_inducing_points_on_the_gpu(kernel):
     Z = be.model_parameters(model)[".inducing_variable.Z"]
     ref = greedy_conditional_variance(np.asarray(train[0]), 24, _InitKernel(model.covar_module.base_kernel).__call__)
     np.testing.assert_array_equal(Z, ref)
+
+
+def test_tf_twin_config_semantics_max_error_vzero_and_joint_optimisation():
+    """tensorflow/models.py:31-51,161-164 behind configure_backend(config_semantics="tf"): `max_error` of the config is the CG
+    tolerance, `vzero` evaluates the bound at v = 0 without CG, `joint_optimization` makes v a trainable parameter whose gradient
+    is d bound / d v = K w - r.  The default ("torch") ignores all three like pytorch/interface.py:315-323."""
+    from cglb_amd.backend import BACKENDS, CGLBConfig, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS
+    from cglb_amd.backend.models import LowerBoundCG
+    be = BACKENDS["hip"]
+    train, _ = _data()
+    N = len(train[1])
+
+    def build(semantics, **cfg_kw):
+        be.configure_backend(logdir="/tmp/cglb_amd_test", keops=False, config_semantics=semantics)
+        be.set_default_float("fp64")
+        be.set_default_jitter("fp64")
+        cfg = CGLBConfig(KERNEL_CONFIGS["rbf"](), INDUCING_VARIABLE_CONFIGS["cv"](12), **cfg_kw)
+        return be.create_model(cfg, train)
+
+    try:
+        # torch semantics: the config's tolerance is ignored
+        m = build("torch", max_error=1e-4)
+        float(-LowerBoundCG(m)(None))
+        hyp = _hyp_of(m)
+        steps_default = orc.objective("rbf", train[0], train[1], hyp, np.zeros(N), True, 1.0).steps
+        assert m.cg_stats.steps == steps_default
+        # tf semantics: the tolerance is consumed
+        m = build("tf", max_error=1e-4)
+        loss = float(-LowerBoundCG(m)(None))
+        ref = orc.objective("rbf", train[0], train[1], hyp, np.zeros(N), True, 1e-4)
+        assert m.cg_stats.steps == ref.steps and ref.steps > steps_default
+        assert loss == pytest.approx(-ref.bound, rel=1e-10)
+        # vzero: no CG, bound at v = 0
+        m = build("tf", vzero=True)
+        loss = float(-LowerBoundCG(m)(None))
+        ref0 = orc.objective("rbf", train[0], train[1], hyp, np.zeros(N), run_cg=False)
+        assert loss == pytest.approx(-ref0.bound, rel=1e-11) and float(m.v_vec.abs().max()) == 0.0 and m.cg_stats is None
+        # joint optimisation: v is a parameter; its gradient matches the oracle's K w - r at a non-trivial v
+        m = build("tf", joint_optimization=True)
+        assert isinstance(m.v_vec, torch.nn.Parameter) and any(p is m.v_vec for p in m.parameters())
+        v0 = 0.3 * np.random.default_rng(0).standard_normal(N)
+        with torch.no_grad():
+            m.v_vec.copy_(torch.from_numpy(v0).reshape(-1, 1))
+        loss = -LowerBoundCG(m)(None)
+        gv, = torch.autograd.grad(loss, [m.v_vec])
+        refj = orc.objective("rbf", train[0], train[1], hyp, v0, run_cg=False, with_grad=True)
+        assert float(loss) == pytest.approx(-refj.bound, rel=1e-11)
+        np.testing.assert_allclose(gv.cpu().numpy().reshape(-1), -refj.grad["v"], rtol=0, atol=1e-10 * np.abs(refj.grad["v"]).max())
+        np.testing.assert_array_equal(m.v_vec.detach().cpu().numpy().reshape(-1), v0)      # no CG ran: v untouched
+    finally:
+        be.configure_backend(logdir="/tmp/cglb_amd_test", keops=False)                    # back to the default semantics
