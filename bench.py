@@ -138,7 +138,13 @@ def main():
     # on a one-GPU box; never set by the real runs)
     force_dist = os.environ.get("CGLB_BENCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
+    stdout_fd = None
     if use_dist:
+        # RCCL prints a version banner on the process's stdout at communicator creation: keep fd 1 pointed at stderr until the JSON
+        # line is printed, so that rank 0's stdout carries exactly that one line
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
@@ -344,7 +350,10 @@ def main():
             "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_grad": roofline_grad, "cpu_baseline": cpu, "secondary": secondary,
             "parity_check": parity,
         }
-        print(json.dumps(record))
+        if stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(stdout_fd, 1)
+        print(json.dumps(record), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
