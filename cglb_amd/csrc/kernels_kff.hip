@@ -97,6 +97,104 @@ __global__ __launch_bounds__(256) void finalize_sum_kernel(const double* __restr
 }
 
 // fixed-order combine of the partial slab c->kpart [jsplit][nrows] (+ noise p, + optional p.out partials)
+// Rectangular pair kernel with the software pipelining of the symmetric kernel (kernels_kff_sym.hip): one (row block, column chunk)
+// work item per wave, the column operand fetched with scalar loads one column ahead of its use, the R table reads of a column issued
+// together.  Serves the implicit Nystrom preconditioner (K_uf r: 1024 rows x N columns; K_fu s: N rows x 1024 columns), whose
+// launches are small: the chunk is chosen so that a launch has thousands of items.  Always the range-clamped 2^x (inducing points may
+// lie outside the training range).  part[k][row] = sum over the columns of chunk k; kff_combine_kernel adds the chunks in order.
+template <typename T, int KIND, int DP, int R, int PREC>
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_rect_kernel(const T* __restrict__ XsRow, const T* __restrict__ xaRow, int64_t nrows,
+                                                       const T* __restrict__ XsCol, const T* __restrict__ xaCol, const T* __restrict__ pcol,
+                                                       int64_t col0, int64_t col1, int64_t chunk, int nchunk, int64_t nitems,
+                                                       T* __restrict__ part, const double* __restrict__ exp_tab) {
+    __shared__ double tab[CGLB_TAB_SIZE];
+    load_exp_table(tab, exp_tab);
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform
+    if (item >= nitems) return;
+    const int64_t rb = item / nchunk, k = item - rb * nchunk;
+    const int64_t rbase = rb * (64 * R);
+    T xi[R][DP], ai[R], acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t row = rbase + r * 64 + lane;
+        row = row < nrows ? row : nrows - 1;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xi[r][d] = XsRow[row * DP + d];
+        ai[r] = (KIND == CGLB_RBF) ? xaRow[row] : T(-0.5) * xaRow[row];  // seed of the Gram chain
+        acc[r] = 0;
+    }
+    const int64_t j0 = col0 + k * chunk;
+    const int64_t j1 = (j0 + chunk < col1) ? j0 + chunk : col1;
+    T xj[DP], aj = xaCol[j0], pj = pcol[j0];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) xj[d] = XsCol[j0 * DP + d];
+    for (int64_t j = j0; j < j1; ++j) {
+        const int64_t jn = (j + 1 < j1) ? j + 1 : j;  // next column (the last one re-reads itself)
+        T xn[DP];
+        const T an = xaCol[jn], pn = pcol[jn];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xn[d] = XsCol[jn * DP + d];
+        __builtin_amdgcn_sched_barrier(0);  // issue the prefetch first; it is consumed a whole column later
+        T gram[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            T g = ai[r];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) g = tfma<T>(xi[r][d], xj[d], g);
+            gram[r] = g;
+        }
+        KappaPend<T> kp[R];
+        kappa_hot_begin_batch<T, KIND, true, false, PREC, R>(gram, aj, tab, kp);
+        __builtin_amdgcn_sched_barrier(0);  // all R table reads are in flight here ...
+#pragma unroll
+        for (int r = 0; r < R; ++r) kappa_hot_poly<T, KIND, PREC>(kp[r]);
+        __builtin_amdgcn_sched_barrier(0);  // ... and are first needed here
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = tfma<T>(kappa_hot_end<T, KIND>(kp[r]), pj, acc[r]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[r]));  // keep the accumulation of a column in its column
+        __builtin_amdgcn_sched_barrier(0);
+        aj = an;
+        pj = pn;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xj[d] = xn[d];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = rbase + r * 64 + lane;
+        if (row < nrows) part[k * nrows + row] = acc[r];
+    }
+}
+
+// Same sum for many slabs and few rows (K_uf r of the implicit preconditioner: ~900 slabs x 1024 rows): a block takes 64 rows, its
+// 16 waves add the slabs g, g+16, ... (4 loads in flight per lane) and the 16 partial sums are added in fixed order through LDS.
+template <typename T>
+__global__ __launch_bounds__(1024) void kff_combine_wide_kernel(const T* __restrict__ part, int jsplit, int64_t nrows, T var, T* __restrict__ out) {
+    __shared__ T gsum[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (i < nrows) {
+        int js = g;
+        for (; js + 48 < jsplit; js += 64) {
+            a0 += part[(int64_t)js * nrows + i];
+            a1 += part[(int64_t)(js + 16) * nrows + i];
+            a2 += part[(int64_t)(js + 32) * nrows + i];
+            a3 += part[(int64_t)(js + 48) * nrows + i];
+        }
+        for (; js < jsplit; js += 16) a0 += part[(int64_t)js * nrows + i];
+    }
+    gsum[g][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && i < nrows) {
+        T s = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += gsum[q][lane];
+        out[i] = var * s;
+    }
+}
+
 template <typename T>
 static int kff_combine(cglb_ctx* c, int64_t jsplit, int64_t nrows, T* out, const T* pdiag, T noise, double* pdot_slot) {
     if (c->kff_skip_combine) return CGLB_OK;
@@ -179,32 +277,56 @@ static int kff_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrow
 // Rectangular kernel product with explicit row and column operands (hot-scaled):
 //   out[i] = var * sum_{j in [col0,col1)} kappa(row_i, col_j) pcol[j]      (pcol is indexed by the absolute column index)
 // Used by the implicit Nystrom preconditioner (K_uf r and K_fu s).
-int launch_pairs_rect(cglb_ctx* c, const void* XsRow, const void* xaRow, int64_t nrows, const void* XsCol, const void* xaCol, const void* pcol,
-                      int64_t col0, int64_t col1, void* out) {
-    if (nrows == 0) return CGLB_OK;
-    const size_t need = (size_t)512 * nrows * c->esz;
+template <typename T, int KIND, int DP>
+static int kff_rect_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t nrows, const T* XsCol, const T* xaCol, const T* pcol, int64_t col0,
+                            int64_t col1, T* out) {
+    constexpr int R = sizeof(T) == 8 ? ((DP <= 4) ? 8 : (DP <= 8) ? 4 : (DP <= 16 ? 2 : 1)) : ((DP <= 4) ? 8 : (DP <= 16) ? 4 : 2);
+    const int64_t ncols = col1 - col0;
+    const int64_t nrb = (nrows + 64 * R - 1) / (64 * R);
+    // enough (row block, chunk) items to fill the chip (~4k waves), chunks of at least 64 columns, multiples of 16
+    int64_t nchunk = (4096 + nrb - 1) / nrb;
+    if (nchunk > (ncols + 63) / 64) nchunk = (ncols + 63) / 64;
+    if (nchunk > 2048) nchunk = 2048;
+    if (nchunk < 1) nchunk = 1;
+    int64_t chunk = (ncols + nchunk - 1) / nchunk;
+    chunk = (chunk + 15) / 16 * 16;
+    nchunk = (ncols + chunk - 1) / chunk;
+    const size_t need = (size_t)nchunk * nrows * sizeof(T);
     if (need > c->ppart_cap) {
         if (c->ppart) HIP_CHECK(c, hipFree(c->ppart));
         c->ppart = nullptr;
         HIP_CHECK(c, hipMalloc(&c->ppart, need));
         c->ppart_cap = need;
     }
+    const int64_t nitems = nrb * nchunk;
+    const unsigned grid = (unsigned)((nitems + 3) / 4);
+    CGLB_DISPATCH_PREC(c, hipLaunchKernelGGL((kff_rect_kernel<T, KIND, DP, R, PREC>), dim3(grid), dim3(256), 0, c->stream, XsRow, xaRow, nrows, XsCol, xaCol,
+                                             pcol, col0, col1, chunk, (int)nchunk, nitems, (T*)c->ppart, (const double*)c->exp_tab));
+    CGLB_LAUNCH_CHECK(c);
+    if (nchunk > 32) {  // many slabs: the one-thread-per-row sum would be a serial chain of nchunk loads on nrows threads
+        hipLaunchKernelGGL((kff_combine_wide_kernel<T>), dim3((unsigned)((nrows + 63) / 64)), dim3(1024), 0, c->stream, (const T*)c->ppart, (int)nchunk, nrows,
+                           (T)c->var, out);
+    } else {
+        const int cgrid = (int)((nrows + 255) / 256);
+        hipLaunchKernelGGL((kff_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)c->ppart, (int)nchunk, nrows, (T)c->var, (T)0,
+                           (const T*)nullptr, out, (double*)nullptr);
+    }
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
+// Rectangular kernel product with explicit row and column operands (hot-scaled):
+//   out[i] = var * sum_{j in [col0,col1)} kappa(row_i, col_j) pcol[j]      (pcol is indexed by the absolute column index)
+// Used by the implicit Nystrom preconditioner (K_uf r and K_fu s).
+int launch_pairs_rect(cglb_ctx* c, const void* XsRow, const void* xaRow, int64_t nrows, const void* XsCol, const void* xaCol, const void* pcol,
+                      int64_t col0, int64_t col1, void* out) {
+    if (nrows == 0) return CGLB_OK;
     if (col1 <= col0) {
         HIP_CHECK(c, hipMemsetAsync(out, 0, (size_t)nrows * c->esz, c->stream));
         return CGLB_OK;
     }
-    int64_t ns = 1;
-    const bool saved = c->exp_clamp;
-    c->exp_clamp = true;  // inducing points may lie outside the training range
-    int rc = CGLB_OK;
-    CGLB_DISPATCH_ALL(c, rc = (kff_pairs_range<T, KIND, DP>(c, (const T*)XsRow, (const T*)xaRow, nrows, (const T*)pcol, col0, col1, (T*)c->ppart, 512,
-                                                            &ns, (const T*)XsCol, (const T*)xaCol)));
-    c->exp_clamp = saved;
-    CGLB_TRY(rc);
-    const int cgrid = (int)((nrows + 255) / 256);
-    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((kff_combine_kernel<T>), dim3(cgrid), dim3(256), 0, c->stream, (const T*)c->ppart, (int)ns, nrows,
-                                                 (T)c->var, (T)0, (const T*)nullptr, (T*)out, (double*)nullptr));
-    CGLB_LAUNCH_CHECK(c);
+    CGLB_DISPATCH_ALL(c, return (kff_rect_generic<T, KIND, DP>(c, (const T*)XsRow, (const T*)xaRow, nrows, (const T*)XsCol, (const T*)xaCol, (const T*)pcol,
+                                                               col0, col1, (T*)out)));
     return CGLB_OK;
 }
 
