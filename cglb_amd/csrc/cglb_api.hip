@@ -352,7 +352,7 @@ int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter
             CGLB_TRY(launch_residual(c, c->w_r, b, c->w_Kv));
         }
         CGLB_TRY(precond_single(c, c->w_r, c->w_z, s_nrz));                                         // :73
-        CGLB_TRY(launch_update_p(c, c->w_p, c->w_z, s_nrz, s_rz, restart));                         // :75
+        CGLB_TRY(launch_update_p(c, c->w_p, c->w_z, s_nrz, s_rz, restart, -1, true));               // :75 (+ weighted copy for :66)
         std::swap(s_rz, s_nrz);                                                                     // :76
         HIP_CHECK(c, hipMemcpyAsync(c->host_scal, s_rz, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(c, hipEventRecord(c->scal_event, c->stream));

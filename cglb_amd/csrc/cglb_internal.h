@@ -168,7 +168,7 @@ int launch_dot(cglb_ctx* c, const void* a, const void* b, int64_t n, double* out
 int launch_update_v_r(cglb_ctx* c, void* v, void* r, const void* p, const void* Ap, const double* rz, const double* pAp, int update_r, int64_t n = -1);
 int launch_residual(cglb_ctx* c, void* r, const void* b, const void* Kv, int64_t n = -1);
 int launch_axpy(cglb_ctx* c, void* y, double alpha, const void* x, int64_t n);
-int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart, int64_t n = -1);
+int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart, int64_t n = -1, bool fuse = false);
 int launch_gemv_u(cglb_ctx* c, const void* r_local, void* u_out);               // u = A_loc r
 int launch_tri_apply(cglb_ctx* c, const void* u, void* t_out);                  // t = LB^-T LB^-1 u
 int launch_precond_z(cglb_ctx* c, const void* r_local, const void* t, void* z_local, double* rz_slot, void* rz_slot_T = nullptr);

@@ -102,11 +102,14 @@ static inline bool fuse_weights(const cglb_ctx* c, int64_t n) {
     return c->kind == CGLB_RBF && !c->exp_clamp && c->have_hypers && n == c->N;
 }
 
-int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart, int64_t n) {
+// fuse: also write the weighted copy for the NEXT symmetric mat-vec of p.  Only for callers that own the loop (the fused PCG and the
+// segmented multi-GPU update): the copy is valid only while p is not modified before that mat-vec, which a caller of the generic
+// cglb_vec_update_p / cglb_shard_update_p entry points has not promised.
+int launch_update_p(cglb_ctx* c, void* p, const void* z, const double* new_rz, const double* rz, int restart, int64_t n, bool fuse) {
     if (n < 0) n = c->nloc;
     if (n == 0) return CGLB_OK;
     const int grid = vec_grid(n, 256);
-    const bool fw = fuse_weights(c, n);
+    const bool fw = fuse && fuse_weights(c, n);
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((update_p_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (T*)p, (const T*)z,
                                                  n, new_rz, rz, restart, fw ? (const T*)c->wh : (const T*)nullptr, (T*)c->pwh));
     CGLB_LAUNCH_CHECK(c);

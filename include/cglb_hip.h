@@ -157,7 +157,8 @@ int cglb_vec_residual(cglb_ctx* ctx, int64_t n, void* r, const void* b, const vo
 int cglb_vec_update_p(cglb_ctx* ctx, int64_t n, void* p, const void* z, const void* new_rz, const void* rz, int restart);
 /* p = z + p * (new_rz / rz) (or p = z) with z all-gathered in `world` slices of per + 1 elements (cglb_shard_precond_z_seg) and
  * new_rz = the sum, in rank order, of the slices' extra elements: the stop-test scalar is then identical on every rank by
- * construction.  new_rz: dev double[1], written; rz: dev double[1], the previous value (conjugate_gradient.py:75-76). */
+ * construction.  new_rz: dev double[1], written; rz: dev double[1], the previous value (conjugate_gradient.py:75-76).
+ * The kernel also prepares the operand of the NEXT cglb_matvec_cyclic(p): p must not be modified in between (the PCG loop does not). */
 int cglb_vec_update_p_seg(cglb_ctx* ctx, int64_t n, int64_t per, int world, void* p, const void* zseg, void* new_rz, const void* rz, int restart);
 int cglb_vec_axpy(cglb_ctx* ctx, int64_t n, double alpha, const void* x, void* y); /* y += alpha x */
 /* objective phase 1 with (K_ff + noise I) v already computed for the local rows; phase 2 unchanged; the local slice of
