@@ -1,5 +1,5 @@
 """All K_ff mat-vec kernel variants against the dense oracle / the blocked C oracle, including ragged sizes
-(N not a multiple of 16/64/256), D in {1,3,8,16}, both kernels."""
+(N not a multiple of 16/64/256), D in {1,3,5,8,12,16,24,32} (every padded dimension of dispatch.h up to CGLB_MAX_D), both kernels."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("kind", ["rbf", "matern32"])
-@pytest.mark.parametrize("N,D", [(257, 1), (1000, 3), (4099, 8), (2500, 16), (333, 5)])
+@pytest.mark.parametrize("N,D", [(257, 1), (1000, 3), (4099, 8), (2500, 16), (333, 5), (700, 12), (600, 24), (520, 32)])
 def test_matvec_variants(variant, kind, N, D):
     from cglb_amd.hip_context import HipContext
     X, y, Z = orc.synthetic_problem(N, D, 8, seed=N + D)
