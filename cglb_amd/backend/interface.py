@@ -219,7 +219,8 @@ def _optimize_cglb(model: CGLB, dataset, num_steps: int, logger: Logger, optimiz
     with logger.no_recording():                             # :494-501
         _loss = lbfgs_closure()
         _grads = torch.autograd.grad(_loss, params)
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():                       # :499-501
+            torch.cuda.synchronize()
     logger.timer.reset()
     logger.timer.start()
 

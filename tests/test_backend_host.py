@@ -181,3 +181,66 @@ def test_json_artefacts_use_the_json_tricks_ndarray_encoding(tmp_path):
     assert back["loss"] == [3.0, 2.0] and back["id"] == "run-1" and back["steps-per-feval"] == [5, 3, 0]
     assert isinstance(back["params"][1][".kernel.lengthscales"], np.ndarray) and back["params"][1][".kernel.lengthscales"].tolist() == [1.1, 2.1]
     assert isinstance(back["cg/steps"][0], np.ndarray) and back["cg/steps"][0].shape == ()
+
+
+def test_optimize_schedule_four_rounds_without_inducing_points_in_the_last_two(monkeypatch, tmp_path):
+    """pytorch/interface.py:445-543 on the host, with the solver and SciPy replaced by recorders: a warm-up evaluation outside the
+    recording, then up to four `minimize` rounds, each with maxiter = the steps still left, the third and fourth without the
+    inducing points in the variable list (:527-529), the step callback clearing the cache flag and feeding the logger (:479-481)."""
+    from types import SimpleNamespace
+    from cglb_amd.backend import interface
+    from cglb_amd.backend.callbacks import Logger
+    from cglb_amd.backend.conjugate_gradient import ConjugateGradientStats
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.noise = torch.nn.Parameter(torch.zeros(1, dtype=torch.float64))
+            self.covar_module = torch.nn.Module()
+            self.covar_module.inducing_points = torch.nn.Parameter(torch.zeros(4, 2, dtype=torch.float64))
+            self.ls = torch.nn.Parameter(torch.zeros(2, dtype=torch.float64))
+            self.cg_stats = ConjugateGradientStats(3, 0.5)
+
+    class FakeBound:
+        instances = []
+
+        def __init__(self, model):
+            self.model, self.cached_v_vec, self.calls = model, True, 0
+            FakeBound.instances.append(self)
+
+        def __call__(self, data):
+            self.calls += 1
+            return -sum((p ** 2).sum() for p in self.model.parameters()) - 1.0
+
+    rounds = []
+
+    class FakeScipy:
+        nits = iter([3, 2, 4, 100])
+
+        def minimize(self, closure, variables, options=None, step_callback=None, **kw):
+            nit = min(next(FakeScipy.nits), options["maxiter"])
+            rounds.append(dict(ids=[id(v) for v in variables], maxiter=options["maxiter"], ftol=options["ftol"], gtol=options["gtol"]))
+            for k in range(nit):
+                closure()
+                step_callback(k, variables, [v.detach() for v in variables])
+            return SimpleNamespace(nit=nit, nfev=nit, fun=0.0, status=0)
+
+    monkeypatch.setattr(interface, "LowerBoundCG", FakeBound)
+    monkeypatch.setattr(interface, "Scipy", FakeScipy)
+    model = Model()
+    logger = Logger(str(tmp_path), lambda: {"loss": 1.0}, lambda: {}, holdout_interval=1, include_feval_log=True, verbose=False)
+    results = interface._optimize_cglb(model, None, 20, logger, "scipy")
+    ips = id(model.covar_module.inducing_points)
+    assert [r.nit for r in results] == [3, 2, 4, 11]                      # never more than four rounds; the last takes what is left
+    assert [r["maxiter"] for r in rounds] == [20, 17, 15, 11]
+    assert all(r["ftol"] == 0.0 and r["gtol"] == 0.0 for r in rounds)
+    assert ips in rounds[0]["ids"] and ips in rounds[1]["ids"] and ips not in rounds[2]["ids"] and ips not in rounds[3]["ids"]
+    assert len(rounds[2]["ids"]) == len(rounds[0]["ids"]) - 1
+    bound = FakeBound.instances[-1]
+    assert bound.calls == 1 + 20 and bound.cached_v_vec is False            # warm-up + one per closure call; flag reset by the callback
+    assert len(logger.logs["steps-per-feval"]) == 20                        # the warm-up evaluation is not recorded (:494-501)
+    assert len(logger.logs["loss"]) == 20                                   # holdout_interval = 1: metrics at every accepted step
+    # the schedule stops as soon as the budget is used up
+    FakeScipy.nits = iter([20])
+    rounds.clear()
+    assert [r.nit for r in interface._optimize_cglb(Model(), None, 20, logger, "scipy")] == [20] and len(rounds) == 1
