@@ -174,6 +174,7 @@ int setup_local_impl(cglb_ctx* c) {
     if (!c->have_data || !c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_data and set_hypers must precede setup");
     const int M = c->M;
     // K_uu + jitter I -> L (models.py:200-202)
+    c->have_Linv = false;
     CGLB_TRY(launch_kuu(c));
     if (c->chol_mode == 1) CGLB_TRY(launch_cholesky_lower(c, c->Lc, (int*)c->info_dev));  // blocked LDS Cholesky (kernels_chol.hip)
     else BLAS_CHECK(c, xpotrf(c->blas, rocblas_fill_lower, M, (T*)c->Lc, M, c->info_dev));
@@ -190,6 +191,7 @@ int setup_local_impl(cglb_ctx* c) {
         HIP_CHECK(c, hipMemcpyAsync(&info_inv, c->info_dev + 2, sizeof(info_inv), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(c, hipStreamSynchronize(c->stream));
         if (info_inv != 0) return cglb_fail(c, CGLB_ERR_NOT_PD, "inverse of L failed: zero pivot " + std::to_string(info_inv));
+        c->have_Linv = true;
     }
     // K_uf shard -> A = L^-1 K_uf / sigma  (models.py:196-197, :206).  Column-major view: At (nloc x M) L^T = Kuf^T / sigma.
     if (c->nloc > 0) {
@@ -386,6 +388,20 @@ int obj_phase2(cglb_ctx* c, const void* v_full, const void* u, double* sc_partia
     return CGLB_OK;
 }
 
+// L^-1 (lower, column-major) for the gradient algebra: one rocBLAS trtri per evaluation, after which the three M x M triangular
+// solves and the trsv of the adjoints are plain GEMMs / a row-dot kernel (rocBLAS trsm with an M x M right-hand side inverts the
+// 128-wide diagonal blocks itself and then issues ~20 small GEMMs: 0.27 ms each at M = 1024, trsv 0.17 ms).  L comes from a
+// successful Cholesky factorisation (positive diagonal), so the inversion cannot meet a zero pivot.
+template <typename T>
+int ensure_Linv(cglb_ctx* c) {
+    if (c->have_Linv) return CGLB_OK;
+    const int M = c->M;
+    HIP_CHECK(c, hipMemcpyAsync(c->Linv, c->Lc, (size_t)M * M * c->esz, hipMemcpyDeviceToDevice, c->stream));
+    BLAS_CHECK(c, xtrtri(c->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, M, (T*)c->Linv, M, c->info_dev + 2));
+    c->have_Linv = true;
+    return CGLB_OK;
+}
+
 template <typename T>
 int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const void* aw, double* out, const void* u_full_cyclic = nullptr) {
     const int M = c->M, D = c->D;
@@ -399,19 +415,33 @@ int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const voi
                         &zero, (T*)c->Mtmp, M));
     hipLaunchKernelGGL((trace_kernel<T>), dim3(1), dim3(256), 0, c->stream, (const T*)c->Mtmp, M, c->scal + S_TRBINV);
     // c = Kuu^-1 Kuf w = sigma L^-T (A w); mhalf = -c/2
-    HIP_CHECK(c, hipMemcpyAsync(c->w_t2, aw, (size_t)M * c->esz, hipMemcpyDeviceToDevice, c->stream));
-    BLAS_CHECK(c, xtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, (const T*)c->Lc, M, (T*)c->w_t2, 1));
+    const bool use_inv = c->grad_trsm == 0;
+    if (use_inv) {
+        CGLB_TRY(ensure_Linv<T>(c));
+        if (!c->Mtmp3) CGLB_TRY(dalloc(c, &c->Mtmp3, (size_t)M * M * c->esz));
+        CGLB_TRY(launch_tri_rowdot(c, c->Linv, aw, 0, c->w_t2));  // (L^-T x)_i = column i of L^-1 (contiguous) . x
+    } else {
+        HIP_CHECK(c, hipMemcpyAsync(c->w_t2, aw, (size_t)M * c->esz, hipMemcpyDeviceToDevice, c->stream));
+        BLAS_CHECK(c, xtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, (const T*)c->Lc, M, (T*)c->w_t2, 1));
+    }
     hipLaunchKernelGGL((scale2_kernel<T>), dim3(grid1d(M)), dim3(256), 0, c->stream, (const T*)c->w_t2, (int64_t)M, (T)sigma, (T*)c->w_t2,
                        (T)(-0.5 * sigma), (T*)c->w_t);
     // Guf = (1/sigma) L^-T (I/tau - B^-1) A   (+ c w^T applied on the fly)
     hipLaunchKernelGGL((mat_combine_kernel<T>), dim3(grid1d_full((int64_t)M * M)), dim3(256), 0, c->stream, (T*)c->Mtmp2, M, (T)(1.0 / tau), (T)-1,
                        (const T*)c->Mtmp, (T)0, (const T*)nullptr);
     const T inv_sigma = (T)(1.0 / sigma);
-    BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, M, &inv_sigma,
-                        (const T*)c->Lc, M, (T*)c->Mtmp2, M));
+    const T* Tuf = (const T*)c->Mtmp2;  // (1/sigma) L^-T (I/tau - B^-1)
+    if (use_inv) {
+        BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &inv_sigma, (const T*)c->Linv, M,
+                            (const T*)c->Mtmp2, M, &zero, (T*)c->Mtmp3, M));
+        Tuf = (const T*)c->Mtmp3;
+    } else {
+        BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, M, &inv_sigma,
+                            (const T*)c->Lc, M, (T*)c->Mtmp2, M));
+    }
     if (c->nloc > 0) {
         BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, (int)c->nloc, M, M, &one, (const T*)c->At, (int)c->lda,
-                            (const T*)c->Mtmp2, M, &zero, (T*)c->Guf, (int)c->lda));
+                            Tuf, M, &zero, (T*)c->Guf, (int)c->lda));
         CGLB_TRY(launch_grad_kuf(c, c->w_t2, c->w_z, out));
         if (!u_full_cyclic) {
             // u = w + v/2 ; N^2 bilinear pass over the local rows
@@ -432,10 +462,17 @@ int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const voi
         // Guu = L^-T [ (I - B^-1)/2 - (AA^T)/(2 tau) ] L^-1  - c c^T/2
         hipLaunchKernelGGL((mat_combine_kernel<T>), dim3(grid1d_full((int64_t)M * M)), dim3(256), 0, c->stream, (T*)c->Mtmp, M, (T)0.5, (T)-0.5,
                            (const T*)c->Mtmp, (T)(-0.5 / tau), (const T*)c->AAt);
-        BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, M, &one,
-                            (const T*)c->Lc, M, (T*)c->Mtmp, M));
-        BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, M, M, &one,
-                            (const T*)c->Lc, M, (T*)c->Mtmp, M));
+        if (use_inv) {  // L^-T S L^-1 as two GEMMs
+            BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one, (const T*)c->Linv, M,
+                                (const T*)c->Mtmp, M, &zero, (T*)c->Mtmp3, M));
+            BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_none, rocblas_operation_none, M, M, M, &one, (const T*)c->Mtmp3, M,
+                                (const T*)c->Linv, M, &zero, (T*)c->Mtmp, M));
+        } else {
+            BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, M, &one,
+                                (const T*)c->Lc, M, (T*)c->Mtmp, M));
+            BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, M, M, &one,
+                                (const T*)c->Lc, M, (T*)c->Mtmp, M));
+        }
         CGLB_TRY(launch_grad_kuu(c, c->Mtmp, c->w_t2, c->w_t, out));
         hipLaunchKernelGGL(grad_scalar_terms_kernel, dim3(1), dim3(64), 0, c->stream, out, D, sc, (const double*)(c->scal + S_TRBINV), (double)c->N,
                            (double)M, f, s, tau, c->trace_AAt);
@@ -543,7 +580,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     if (!c) return CGLB_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->Xhsq, c->xah, c->wh, c->pwh, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Guf,
+    void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->Xhsq, c->xah, c->wh, c->pwh, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Mtmp3, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
                     c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -575,6 +612,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
         c->precision = (int)value;
     }
     else if (!strcmp(name, "chol_mode")) c->chol_mode = (int)value;
+    else if (!strcmp(name, "grad_trsm")) c->grad_trsm = (int)value;
     else if (!strcmp(name, "precond_mode")) { c->precond_mode = (int)value; c->have_local = c->have_terms = false; }
     else return cglb_fail(c, CGLB_ERR_BAD_ARG, std::string("unknown option ") + name);
     return CGLB_OK;
@@ -1031,7 +1069,7 @@ int cglb_time_kernel(cglb_ctx* c, int which, int reps, double* ms_avg) {
     if (c) c->obj_valid = false;
     if (!c || !ms_avg || reps <= 0) return CGLB_ERR_BAD_ARG;
     if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede timing");
-    if (which != 0 && which != 3 && which != 4) CGLB_TRY(require_terms(c));
+    if (which != 0 && which != 3 && which != 4 && which != 5) CGLB_TRY(require_terms(c));
     HIP_CHECK(c, hipSetDevice(c->device));
     // operands: y as a generic vector (values do not change the instruction stream)
     hipEvent_t e0, e1;
@@ -1047,6 +1085,11 @@ int cglb_time_kernel(cglb_ctx* c, int which, int reps, double* ms_avg) {
             const int r = launch_kff_sym_cyclic(c, c->y, c->w_pfull);
             c->kff_skip_combine = false;
             return r;
+        }
+        if (which == 5) {  // K_uu + jitter I and its blocked Cholesky (the first factorisation of the common terms)
+            c->have_local = c->have_terms = false;  // L is overwritten without the clean-up of the strict upper triangle
+            CGLB_TRY(launch_kuu(c));
+            return launch_cholesky_lower(c, c->Lc, (int*)c->info_dev);
         }
         if (which == 3) {  // the pair kernel of the mat-vec alone (what rocprofv3 lists as kff_matvec_kernel)
             c->kff_skip_combine = true;

@@ -1,7 +1,13 @@
 // Blocked lower Cholesky of the two small M x M matrices of the common terms (K_uu + jitter I and B = A A^T + I,
 // reference models.py:202, :210).  rocSOLVER's potrf spends 2.9 ms on a 1024^2 matrix (latency of ~40 small kernels with a
-// 155-us unblocked panel step); this right-looking version factors the 64 x 64 diagonal block in the registers of one wave, solves the
-// panel below it with one row per thread against scalar-loaded factors, and leaves the trailing rank-64 update to rocBLAS syrk (a true dense contraction).
+// 155-us unblocked panel step).  This right-looking version runs three small kernels per 64-column step.  They are written as
+// ROLLED loops on purpose: a one-wave, fully unrolled factorisation of the 64 x 64 block (rows in registers, operands by
+// v_readlane or LDS broadcast) is 50-60 KB of straight-line code that runs once on a cold instruction cache, and measured
+// 38 us (readlane form) / 90 us (LDS form) - the time of fetching the instructions, not of executing them.
+//   diag    64 x 64 diagonal block, 1024 threads: lane = row, wave = column group; one barrier per column
+//   panel   rows below it, one wave per row (lane = column), the finished entry broadcast with v_readlane (no barrier)
+//   update  trailing rank-64 update A22 -= P P^T, one 64 x 64 tile of the lower triangle per workgroup
+//           (rocBLAS syrk splits this shape into a diagonal kernel and 5-7 small GEMMs: ~45 us of launches per step).
 // Column-major, in place; the strict upper triangle is not referenced or modified.
 #include "devmath.h"
 #include "dispatch.h"
@@ -9,8 +15,100 @@
 #ifndef CHOL_NB
 #define CHOL_NB 64
 #endif
+static_assert(CHOL_NB == 64, "the kernels map the 64 rows / columns of a block to the lanes of a wave");
 
-__device__ __forceinline__ double readlane_t(double v, int lane) {
+// sqrt(s) and 1/sqrt(s) of a positive pivot: v_rsq_f64 seed, two Newton steps, one residual correction each (both to ~1 ulp)
+__device__ __forceinline__ void pivot_root(double s, double& root, double& rinv) {
+    double y = __builtin_amdgcn_rsq(s);
+    const double h = 0.5 * s;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-(h * y), y, 0.5);
+        y = __builtin_fma(y, e, y);
+    }
+    double g = s * y;
+    g = __builtin_fma(__builtin_fma(-g, g, s), 0.5 * y, g);
+    root = g;
+    rinv = __builtin_fma(__builtin_fma(-g, y, 1.0), y, y);
+}
+__device__ __forceinline__ void pivot_root(float s, float& root, float& rinv) {
+    root = __builtin_sqrtf(s);
+    rinv = 1.0f / root;
+}
+// 1/s for the rank-1 update (the only arithmetic between reading a pivot and the next column): v_rcp_f64 + two Newton steps
+__device__ __forceinline__ double pivot_rcp(double s) {
+    double y = __builtin_amdgcn_rcp(s);
+    y = __builtin_fma(__builtin_fma(-s, y, 1.0), y, y);
+    return __builtin_fma(__builtin_fma(-s, y, 1.0), y, y);
+}
+__device__ __forceinline__ float pivot_rcp(float s) { return 1.0f / s; }
+
+// Factor the nb x nb diagonal block at (k0, k0).  Thread (r = lane, w = wave) holds A[r][w + 16 k], k = 0..3, in four registers.
+// Step j (column j = 16 jq + jj lives in wave jj, register jq): the owning wave puts the column as it stands ("raw":
+// a_rj after the updates of columns < j) into LDS; after ONE barrier every thread reads the pivot p = a_jj, its row entry a_rj
+// and the entries a_cj of its own columns c > j, and applies a_rc -= (a_rj a_cj) / p  (= L_rj L_cj).  The square roots are
+// taken after the loop (L_rj = a_rj / sqrt(p_j) from the raw columns kept in the registers and the pivots kept in LDS), so that
+// the chain from one column to the next is LDS write -> barrier -> LDS read -> reciprocal -> 2 flops.  Registers of the strict
+// upper triangle collect garbage that is never read.  The raw-column buffer is double-buffered: a wave may write column j + 1
+// while a slower one still reads column j.
+// A short block (nb < 64, last block of a ragged matrix) is padded with the identity.  info[0] receives k0 + j + 1 for the
+// first non-positive pivot (only if still 0); the block is then left unwritten.  Dblk receives a dense transposed copy of the
+// factored block (Dblk[t * 64 + c] = L[c][t] for c > t, zero elsewhere) plus the reciprocal diagonal for the panel kernel.
+template <typename T>
+__global__ __launch_bounds__(1024) void chol_diag_kernel(T* __restrict__ A, int n, int k0, int nb, int* __restrict__ info,
+                                                         T* __restrict__ Dblk) {
+    __shared__ T colraw[2][CHOL_NB];
+    __shared__ T pivs[CHOL_NB];
+    const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cc = w + 16 * k;
+        T v = (cc == r) ? T(1) : T(0);  // identity padding
+        if (r < nb && cc < nb) v = (cc <= r) ? A[(size_t)(k0 + cc) * n + k0 + r] : T(0);
+        a[k] = v;
+    }
+    int bad = 0;
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+#pragma unroll 1
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * jq + jj;
+            T* buf = colraw[j & 1];
+            if (w == jj) buf[r] = a[jq];
+            __syncthreads();
+            const T piv = buf[j];
+            const T xr = buf[r];
+            const bool ok = piv > T(0);  // false for NaN too; every thread sees the same pivot
+            bad = (!ok && bad == 0) ? j + 1 : bad;
+            if (threadIdx.x == 0) pivs[j] = ok ? piv : T(1);
+            const T rp = pivot_rcp(ok ? piv : T(1));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < jq) continue;
+                const T upd = tfma<T>(-(xr * buf[w + 16 * k]), rp, a[k]);  // the product does not wait for the reciprocal
+                a[k] = (k > jq || w > jj) ? upd : a[k];
+            }
+        }
+    }
+    if (bad != 0) {
+        if (threadIdx.x == 0 && info[0] == 0) info[0] = k0 + bad;
+        return;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cc = w + 16 * k;
+        T root, rinv;
+        pivot_root(pivs[cc], root, rinv);
+        const T l = (r == cc) ? root : (r > cc ? a[k] * rinv : T(0));
+        if (r < nb && cc <= r && cc < nb) A[(size_t)(k0 + cc) * n + k0 + r] = l;
+        Dblk[cc * CHOL_NB + r] = (r > cc) ? l : T(0);  // strictly lower part, transposed: Dblk[t][c] = L[c][t]
+        if (r == cc) Dblk[CHOL_NB * CHOL_NB + cc] = rinv;
+    }
+}
+
+__device__ __forceinline__ double readlane_t(double v, int lane) {  // lane: wave-uniform, may be a run-time value
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
@@ -19,112 +117,94 @@ __device__ __forceinline__ float readlane_t(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// Factor the nb x nb diagonal block at (k0, k0) with ONE wave: lane r owns row r of the block in registers (fully unrolled,
-// static indices).  What another lane needs from row j — L[j][t], t < j — is taken straight out of lane j's registers with
-// v_readlane into SGPRs and used as the scalar operand of the fma: no LDS, no barrier (an LDS broadcast per term exposed its
-// full latency 2016 times: 58 us; this form is issue-bound).
-//   step j:  s_r = a_r[j] - sum_{t<j} L[r][t] L[j][t]  (all lanes);  L[j][j] = sqrt(s_j);  L[r][j] = s_r / L[j][j]  (r > j)
-// A short block (nb < 64, last block of a ragged matrix) is padded with the identity.  info[0] receives k0 + j + 1 for the
-// first non-positive pivot (only if still 0); the block is then left unwritten.  Dblk receives a dense transposed copy of the
-// factored block (Dblk[t * 64 + c] = L[c][t] for c > t, zero elsewhere) plus the reciprocal diagonal for the panel kernel.
+// Panel below the diagonal block: X L_kk^T = P.  ONE WAVE PER ROW of P, lane c holds P[row][c]; 16 rows per workgroup share one
+// LDS copy of the factor block (stored transposed by the diag kernel: column t of L_kk is contiguous, conflict-free).
+// Right-looking substitution: x_t = p_t / L_tt is final in lane t, reaches the other lanes through v_readlane (run-time lane
+// index: the loop stays rolled), and every later entry takes p_c -= x_t L[c][t]; the chain from step to step is mul - readlane -
+// fma, the LDS reads of a block of 8 steps are issued ahead of it.  (Global loads of the columns with a register prefetch
+// queue measured 21 us per panel: the wait counters are drained at every trip of a rolled loop.)
 template <typename T>
-__global__ __launch_bounds__(64) void chol_diag_kernel(T* __restrict__ A, int n, int k0, int nb, int* __restrict__ info,
-                                                       T* __restrict__ Dblk) {
-    const int r = threadIdx.x;
-    T a[CHOL_NB];
+__global__ __launch_bounds__(1024) void chol_panel_kernel(T* __restrict__ A, int n, int k0, const T* __restrict__ Dblk) {
+    __shared__ T Ls[CHOL_NB * CHOL_NB + CHOL_NB];
+    for (int i = threadIdx.x; i < CHOL_NB * CHOL_NB + CHOL_NB; i += 1024) Ls[i] = Dblk[i];
+    const int lane = threadIdx.x & 63;
+    const int row = k0 + CHOL_NB + blockIdx.x * 16 + (threadIdx.x >> 6);
+    T p = row < n ? A[(size_t)(k0 + lane) * n + row] : T(0);
+    __syncthreads();
+    if (row >= n) return;  // whole waves leave together
+    const T myrinv = Ls[CHOL_NB * CHOL_NB + lane];
+#pragma unroll 1
+    for (int t0 = 0; t0 < CHOL_NB; t0 += 8) {
+        T lq[8];
 #pragma unroll
-    for (int cc = 0; cc < CHOL_NB; ++cc) {
-        T v = (cc == r) ? T(1) : T(0);  // identity padding
-        if (r < nb && cc < nb) v = (cc <= r) ? A[(size_t)(k0 + cc) * n + k0 + r] : T(0);
-        a[cc] = v;
-    }
-    int bad = 0;
-    // (a right-looking order - scale column j, then update all later columns with readlane'd factors - measured 72 us against
-    //  38 us for this left-looking one: its readlanes depend on the value written just before)
+        for (int i = 0; i < 8; ++i) lq[i] = Ls[(t0 + i) * CHOL_NB + lane];
 #pragma unroll
-    for (int j = 0; j < CHOL_NB; ++j) {
-        T s0 = a[j], s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll
-        for (int t = 0; t < j; ++t) {
-            const T ljt = readlane_t(a[t], j);  // wave-uniform: L[j][t]
-            if ((t & 3) == 0) s0 = tfma<T>(-a[t], ljt, s0);
-            else if ((t & 3) == 1) s1 = tfma<T>(-a[t], ljt, s1);
-            else if ((t & 3) == 2) s2 = tfma<T>(-a[t], ljt, s2);
-            else s3 = tfma<T>(-a[t], ljt, s3);
+        for (int i = 0; i < 8; ++i) {
+            const int t = t0 + i;
+            const T xt = readlane_t(p * myrinv, t);
+            p = (lane == t) ? xt : (lane > t ? tfma<T>(-xt, lq[i], p) : p);
         }
-        const T s = (s0 + s1) + (s2 + s3);
-        const T sj = readlane_t(s, j);
-        T pv = T(1);
-        if (sj > T(0)) pv = sqrt(sj);
-        else if (bad == 0) bad = j + 1;
-        a[j] = (r == j) ? pv : (r > j ? s / pv : T(0));
     }
-    if (bad != 0) {
-        if (r == 0 && info[0] == 0) info[0] = k0 + bad;
-        return;
-    }
-#pragma unroll
-    for (int cc = 0; cc < CHOL_NB; ++cc) {
-        if (r < nb && cc <= r && cc < nb) A[(size_t)(k0 + cc) * n + k0 + r] = a[cc];
-        if (r < CHOL_NB) Dblk[cc * CHOL_NB + r] = (cc < r) ? a[cc] : T(0);  // strictly lower part, transposed: Dblk[t][c] = L[c][t]
-    }
-    T diag = T(1);
-#pragma unroll
-    for (int cc = 0; cc < CHOL_NB; ++cc)
-        if (cc == r) diag = a[cc];
-    if (r < CHOL_NB) Dblk[CHOL_NB * CHOL_NB + r] = T(1) / diag;
+    A[(size_t)(k0 + lane) * n + row] = p;
 }
 
-// Panel below the diagonal block: X L_kk^T = P, one row of P per thread in registers (fully unrolled).  L_kk comes from the
-// dense read-only copy Dblk with wave-uniform indices, i.e. through scalar loads into SGPRs that feed the fma directly.
-// FULL: nb == 64 (every block but a ragged last one): loads and stores are fully static.
-template <typename T, bool FULL>
-__global__ __launch_bounds__(64) void chol_panel_kernel(T* __restrict__ A, int n, int k0, int nb, const T* __restrict__ Dblk) {
-    const int row = k0 + nb + blockIdx.x * 64 + threadIdx.x;
-    if (row >= n) return;
-    T x[CHOL_NB];
-    if (FULL) {
+// Trailing update A22 -= P P^T (lower triangle), P = the 64 panel columns just solved (rows k0 + 64 ... n - 1).  Workgroup
+// (I, J), J <= I, owns the 64 x 64 tile of A22 at block row I, block column J: both 64 x 64 panel slices go to LDS ([k][row]:
+// the 16 rows a quarter-wave reads are contiguous, the other operand is a 4-address broadcast), each thread holds a 4 x 4
+// register tile of products summed in fixed order; the tile of A is loaded together with the panel slices (one memory round trip
+// covers both) and the sum is subtracted once at the end (one rounding at the magnitude of A per step, which fp32 needs).  Rows and columns beyond n (ragged M) are zero-filled and not stored.
+template <typename T>
+__global__ __launch_bounds__(256) void chol_update_kernel(T* __restrict__ A, int n, int k0) {
+    const int I = blockIdx.x, J = blockIdx.y;
+    if (J > I) return;
+    __shared__ T Pi[CHOL_NB][CHOL_NB];
+    __shared__ T Pj[CHOL_NB][CHOL_NB];
+    const int t = threadIdx.x;
+    const int base = k0 + CHOL_NB;
+    const int ti = t & 15, tj = t >> 4;
+    T c0[4][4], acc[4][4];
 #pragma unroll
-        for (int cc = 0; cc < CHOL_NB; ++cc) x[cc] = A[(size_t)(k0 + cc) * n + row];
-    } else {
+    for (int b = 0; b < 4; ++b) {
+        const int cj = base + J * CHOL_NB + tj + 16 * b;
 #pragma unroll
-        for (int cc = 0; cc < CHOL_NB; ++cc) x[cc] = T(0);
-        for (int cc = 0; cc < nb; ++cc) {  // the select chain keeps x[] in registers despite the dynamic bound
-            const T v = A[(size_t)(k0 + cc) * n + row];
-#pragma unroll
-            for (int q = 0; q < CHOL_NB; ++q)
-                if (q == cc) x[q] = v;
+        for (int a = 0; a < 4; ++a) {
+            const int ri = base + I * CHOL_NB + ti + 16 * a;
+            c0[a][b] = (ri < n && cj < n && ri >= cj) ? A[(size_t)cj * n + ri] : T(0);
+            acc[a][b] = T(0);
         }
     }
-    // right-looking substitution: once x[t] is final every later entry is updated independently (63 - t parallel fmas per
-    // step, so a lone wave has no dependent chain to wait on); column t of L_kk is contiguous in Dblk (stored transposed)
+    {
+        const int rl = t & 63;
+        const int ri = base + I * CHOL_NB + rl, rj = base + J * CHOL_NB + rl;
 #pragma unroll
-    for (int t = 0; t < CHOL_NB; ++t) {
-        x[t] *= Dblk[CHOL_NB * CHOL_NB + t];
-#pragma unroll
-        for (int cc = t + 1; cc < CHOL_NB; ++cc) x[cc] = tfma<T>(-x[t], Dblk[t * CHOL_NB + cc], x[cc]);
-    }
-    if (FULL) {
-#pragma unroll
-        for (int cc = 0; cc < CHOL_NB; ++cc) A[(size_t)(k0 + cc) * n + row] = x[cc];
-    } else {
-        for (int cc = 0; cc < nb; ++cc) {
-            T v = T(0);
-#pragma unroll
-            for (int q = 0; q < CHOL_NB; ++q)
-                if (q == cc) v = x[q];
-            A[(size_t)(k0 + cc) * n + row] = v;
+        for (int q = 0; q < CHOL_NB / 4; ++q) {
+            const int k = (t >> 6) + 4 * q;
+            Pi[k][rl] = ri < n ? A[(size_t)(k0 + k) * n + ri] : T(0);
+            Pj[k][rl] = rj < n ? A[(size_t)(k0 + k) * n + rj] : T(0);
         }
     }
-}
-
-static inline rocblas_status xsyrk2(rocblas_handle h, int n, int k, const double* A, int lda, double* C, int ldc) {
-    const double a = -1.0, b = 1.0;
-    return rocblas_dsyrk(h, rocblas_fill_lower, rocblas_operation_none, n, k, &a, A, lda, &b, C, ldc);
-}
-static inline rocblas_status xsyrk2(rocblas_handle h, int n, int k, const float* A, int lda, float* C, int ldc) {
-    const float a = -1.0f, b = 1.0f;
-    return rocblas_ssyrk(h, rocblas_fill_lower, rocblas_operation_none, n, k, &a, A, lda, &b, C, ldc);
+    __syncthreads();
+#pragma unroll 2
+    for (int k = 0; k < CHOL_NB; ++k) {
+        T pi[4], pj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pi[a] = Pi[k][ti + 16 * a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) pj[b] = Pj[k][tj + 16 * b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = tfma<T>(pi[a], pj[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int cj = base + J * CHOL_NB + tj + 16 * b;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ri = base + I * CHOL_NB + ti + 16 * a;
+            if (ri < n && cj < n && ri >= cj) A[(size_t)cj * n + ri] = c0[a][b] - acc[a][b];
+        }
+    }
 }
 
 template <typename T>
@@ -135,17 +215,15 @@ static int cholesky_impl(cglb_ctx* c, T* A, int* info_slot) {
     HIP_CHECK(c, hipMemsetAsync(info_slot, 0, sizeof(int), c->stream));
     for (int k0 = 0; k0 < n; k0 += CHOL_NB) {
         const int nb = n - k0 < CHOL_NB ? n - k0 : CHOL_NB;
-        hipLaunchKernelGGL((chol_diag_kernel<T>), dim3(1), dim3(64), 0, c->stream, A, n, k0, nb, info_slot, Dblk);
+        hipLaunchKernelGGL((chol_diag_kernel<T>), dim3(1), dim3(1024), 0, c->stream, A, n, k0, nb, info_slot, Dblk);
         CGLB_LAUNCH_CHECK(c);
         const int rest = n - k0 - nb;
-        if (rest > 0) {
-            if (nb == CHOL_NB)
-                hipLaunchKernelGGL((chol_panel_kernel<T, true>), dim3((rest + 63) / 64), dim3(64), 0, c->stream, A, n, k0, nb, (const T*)Dblk);
-            else
-                hipLaunchKernelGGL((chol_panel_kernel<T, false>), dim3((rest + 63) / 64), dim3(64), 0, c->stream, A, n, k0, nb, (const T*)Dblk);
+        if (rest > 0) {  // nb == CHOL_NB here: a short block is the last one (rest == 0)
+            hipLaunchKernelGGL((chol_panel_kernel<T>), dim3((rest + 15) / 16), dim3(1024), 0, c->stream, A, n, k0, (const T*)Dblk);
             CGLB_LAUNCH_CHECK(c);
-            // A22 -= P P^T (lower)
-            BLAS_CHECK(c, xsyrk2(c->blas, rest, nb, A + (size_t)k0 * n + k0 + nb, n, A + (size_t)(k0 + nb) * n + k0 + nb, n));
+            const int tn = (rest + CHOL_NB - 1) / CHOL_NB;
+            hipLaunchKernelGGL((chol_update_kernel<T>), dim3(tn, tn), dim3(256), 0, c->stream, A, n, k0);
+            CGLB_LAUNCH_CHECK(c);
         }
     }
     return CGLB_OK;

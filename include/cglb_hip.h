@@ -186,7 +186,8 @@ int cglb_select_inducing(cglb_ctx* ctx, const double* lengthscales, double varia
 int cglb_get_matrix(cglb_ctx* ctx, int which, void* dst);
 /* Average duration (ms, HIP events on the ctx stream) of `reps` back-to-back launches of one kernel family:
  * which = 0: K_ff mat-vec (pair kernel + slab combine), 1: preconditioner apply, 2: gradient bilinear pass,
- * 3: the pair kernel of the mat-vec alone (the dominant kernel), 4: the same for this rank's cyclic share (cglb_set_parallel). */
+ * 3: the pair kernel of the mat-vec alone (the dominant kernel), 4: the same for this rank's cyclic share (cglb_set_parallel),
+ * 5: K_uu + jitter I and its Cholesky factorisation (invalidates the common terms: call cglb_setup again afterwards). */
 int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
 /* In-situ measurement of the dominant kernel: after cglb_set_option(ctx, "k1_profile", 1) every launch of the symmetric pair
  * kernel (in mat-vecs, solves and evaluations alike) is bracketed by HIP events on the context stream; "k1_ms_total" and
@@ -194,7 +195,7 @@ int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
  * "k1_pairs_per_launch": kernel pairs one launch of that kernel evaluates with the current geometry (~N(N+256)/2 on one GPU: the
  * symmetric form visits each unordered pair once) - the unit count of the roofline; "kpart_bytes": size of the partial-sum slabs. */
 int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
-/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" | "sym_order" | "aat_block" | "grad_gram" | "k1_profile" |
+/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "grad_trsm" | "pcg_lookahead" | "sym_order" | "aat_block" | "grad_gram" | "k1_profile" |
  * "precision" (1, default: kernel values to <= 1e-13 relative - degree-3 table polynomial, one-step square root; 0: ~3e-16) ...;
  * returns CGLB_ERR_BAD_ARG if unknown. */
 int cglb_set_option(cglb_ctx* ctx, const char* name, int64_t value);

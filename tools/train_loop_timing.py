@@ -19,9 +19,16 @@ model = be.create_model(CGLBConfig(kernel=KERNEL_CONFIGS["rbf"](), inducing_vari
 torch.cuda.synchronize(); t_create = time.perf_counter() - t0
 data = ((X, y), (X[:1000], y[:1000]))
 logger = Logger("/tmp/cglb_train_timing", be.metrics_fn(model, data), lambda: be.model_parameters(model), holdout_interval=10**9, verbose=False)
+prof = None
+if os.environ.get("PROFILE"):  # host-side view: where the wall time of an evaluation goes (C-ABI calls show as _FuncPtr entries)
+    import cProfile
+    prof = cProfile.Profile(); prof.enable()
 t0 = time.perf_counter()
 results = be.optimize(model, data, steps, logger, "scipy")
 torch.cuda.synchronize(); t_opt = time.perf_counter() - t0
+if prof is not None:
+    import pstats
+    prof.disable(); pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
 nfev = sum(r.nfev for r in results); nit = sum(r.nit for r in results)
 print(f"N={N} D={D} M={M}: create_model {t_create:.2f} s (incl. GPU inducing-point selection); optimize {nit} iterations / {nfev} evaluations "
       f"in {t_opt:.2f} s = {1e3*t_opt/max(nfev,1):.1f} ms per evaluation; final loss {results[-1].fun:.4f}", flush=True)
