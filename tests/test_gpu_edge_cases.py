@@ -166,3 +166,37 @@ def test_gram_form_gradient_pass_against_direct_differences_and_oracle(kind, ls)
         got.append(res.grad["lengthscales"])
         np.testing.assert_allclose(res.grad["lengthscales"], ref.grad["lengthscales"], rtol=2e-8, atol=1e-9 * np.abs(ref.grad["lengthscales"]).max())
     np.testing.assert_allclose(got[1], got[0], rtol=1e-9, atol=1e-11 * np.abs(got[0]).max())
+
+
+@pytest.mark.parametrize("M", [64, 65, 100, 191, 320])
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+def test_ragged_inducing_counts_factorise_like_the_oracle(M, dtype):
+    """M that is not a multiple of the 64-column block of the blocked Cholesky (models.py:202, :210): short last block, ragged panel
+    rows and trailing tiles; the factors, the bound and the gradient follow the dense oracle."""
+    from cglb_amd.hip_context import HipContext
+    N, D = 700, 3
+    X, y, Z = orc.synthetic_problem(N, D, M, seed=M)
+    td = torch.float64 if dtype == "fp64" else torch.float32
+    tol = 1e-9 if dtype == "fp64" else 2e-3
+    hyp = orc.Hypers(np.array([0.9, 1.1, 1.4]), 1.2, 0.3, 0.1, Z, 1e-6 if dtype == "fp64" else 1e-4)
+    ctx = HipContext(X, y, M, "rbf", dtype=td)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+    ctx.setup()
+    terms = orc.common_terms("rbf", X, hyp)
+    L = ctx.get_matrix("L").double().cpu().numpy()
+    LB = ctx.get_matrix("LB").double().cpu().numpy()
+    assert np.all(np.triu(L, 1) == 0) and np.all(np.triu(LB, 1) == 0)
+    np.testing.assert_allclose(L, terms.L, rtol=0, atol=tol * np.abs(terms.L).max())
+    np.testing.assert_allclose(LB, terms.LB, rtol=0, atol=tol * np.abs(terms.LB).max())
+    v = torch.zeros(N, dtype=td, device=ctx.device)
+    res = ctx.objective_and_grad(v, True, 1e-2)
+    ref = orc.objective("rbf", X, y, hyp, np.zeros(N), True, 1e-2)
+    if dtype == "fp64":
+        assert res.steps == ref.steps
+        assert res.bound == pytest.approx(ref.bound, rel=1e-9)
+        refg = orc.objective("rbf", X, y, hyp, v.cpu().numpy(), run_cg=False, with_grad=True).grad
+        np.testing.assert_allclose(res.grad["Z"], refg["Z"], rtol=1e-6, atol=1e-8 * np.abs(refg["Z"]).max())
+        np.testing.assert_allclose(res.grad["lengthscales"], refg["lengthscales"], rtol=1e-7)
+    else:
+        assert abs(res.steps - ref.steps) <= 1 and res.bound == pytest.approx(ref.bound, rel=2e-3)
+

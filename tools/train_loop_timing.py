@@ -19,6 +19,12 @@ model = be.create_model(CGLBConfig(kernel=KERNEL_CONFIGS["rbf"](), inducing_vari
 torch.cuda.synchronize(); t_create = time.perf_counter() - t0
 data = ((X, y), (X[:1000], y[:1000]))
 logger = Logger("/tmp/cglb_train_timing", be.metrics_fn(model, data), lambda: be.model_parameters(model), holdout_interval=10**9, verbose=False)
+# wall time of every objective+gradient call inside optimize (the first ones carry one-time costs: rocBLAS kernels are loaded lazily)
+eval_ms, eval_steps = [], []
+_orig = model.hip.objective_and_grad
+def _timed(*a, **k):
+    t = time.perf_counter(); r = _orig(*a, **k); eval_ms.append(1e3 * (time.perf_counter() - t)); eval_steps.append(r.steps); return r
+model.hip.objective_and_grad = _timed
 prof = None
 if os.environ.get("PROFILE"):  # host-side view: where the wall time of an evaluation goes (C-ABI calls show as _FuncPtr entries)
     import cProfile
@@ -31,4 +37,6 @@ if prof is not None:
     prof.disable(); pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
 nfev = sum(r.nfev for r in results); nit = sum(r.nit for r in results)
 print(f"N={N} D={D} M={M}: create_model {t_create:.2f} s (incl. GPU inducing-point selection); optimize {nit} iterations / {nfev} evaluations "
-      f"in {t_opt:.2f} s = {1e3*t_opt/max(nfev,1):.1f} ms per evaluation; final loss {results[-1].fun:.4f}", flush=True)
+      f"in {t_opt:.2f} s = {1e3*t_opt/max(nfev,1):.1f} ms per evaluation (median of the C-ABI call alone {np.median(eval_ms):.1f} ms, "
+      f"first call {eval_ms[0]:.0f} ms, mean CG steps {np.mean(eval_steps):.1f}); "
+      f"final loss {results[-1].fun:.4f}", flush=True)
