@@ -80,23 +80,25 @@ __device__ __forceinline__ float sqrt_pos(float x) { return __builtin_sqrtf(fmax
 #define CGLB_PREC_FAST 1
 
 // Hot-loop square root for a squared distance that may come out slightly negative (Gram form): the clamp to a tiny positive
-// number replaces both the max(.,0) and the x > 0 select; sqrt_hot(d2 <= 0) = 1e-140, which the Matern profile maps to 1.
-// v_rsq_f64 seed (relative error e0 <= 2^-23, 4 issue slots), one Goldschmidt step (error 1.5 e0^2 = 2.1e-14; 5 more slots with the
-// clamp), and at CGLB_PREC_EXACT a residual correction with the first-order h (error ~ e0^3, below the rounding of the last fma).
+// number replaces both the max(.,0) and the x > 0 select; sqrt_hot(d2 <= 0) = 2e-140, which the Matern profile maps to 1.
+// RETURNS 2 sqrt(x): the hot operand set of Matern-3/2 carries half the nominal scale (cglb_hot_scale), so that the Newton form
+//   y = rsq(x) (v_rsq_f64, relative error e0 <= 2^-23, 4 issue slots),  g = x y,  t = 3 - y g,  2 sqrt(x) = g t (1 - 1.5 e0^2)
+// needs three instructions after the seed where sqrt(x) itself needs four (the factor 1/2 of y' = y (3 - x y^2) / 2 is the one
+// that costs an instruction; a power-of-two scale of the operands is exact).  Error 1.5 e0^2 = 2.1e-14.  At CGLB_PREC_EXACT:
+// one Goldschmidt step plus a residual correction with the first-order h (error ~ e0^3, below the rounding of the last fma), doubled.
 template <int PREC> __device__ __forceinline__ double sqrt_hot(double x) {
     const double xs = fmax(x, 1e-280);
     const double y = __builtin_amdgcn_rsq(xs);
     double g = xs * y;
+    if (PREC != CGLB_PREC_EXACT) return g * __builtin_fma(-y, g, 3.0);
     double h = 0.5 * y;
     const double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
-    if (PREC == CGLB_PREC_EXACT) {
-        const double d = __builtin_fma(-g, g, xs);  // residual ~ e0^2 xs: the first-order h (error e0) is accurate enough to apply it
-        g = __builtin_fma(d, h, g);
-    }
-    return g;
+    const double d = __builtin_fma(-g, g, xs);  // residual ~ e0^2 xs: the first-order h (error e0) is accurate enough to apply it
+    g = __builtin_fma(d, h, g);
+    return g + g;
 }
-template <int PREC> __device__ __forceinline__ float sqrt_hot(float x) { return __builtin_sqrtf(fmaxf(x, 0.0f)); }
+template <int PREC> __device__ __forceinline__ float sqrt_hot(float x) { return 2.0f * __builtin_sqrtf(fmaxf(x, 0.0f)); }
 
 __device__ __forceinline__ double tfma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float tfma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -259,7 +261,8 @@ template <typename T, int KIND, bool CLAMP> __device__ __forceinline__ T kappa_f
 
 // Hot-unit forms (operands scaled so that exponents are in 1/T octave, see exp2_tab_batch):
 //   RBF:      xh = 16 xs, ah = 256 a          kappa = 2^((ah_i + ah_j + xh_i.xh_j)/256)
-//   Matern32: xh = 256 xs, ah = 65536 a       rT = sqrt(max(ah_i + ah_j - 2 xh_i.xh_j, 0)),  kappa = (1 + rT ln2/256) 2^(-rT/256)
+//   Matern32: xh = 128 xs, ah = 16384 a       rT = 2 sqrt(max(ah_i + ah_j - 2 xh_i.xh_j, 0)),  kappa = (1 + rT ln2/256) 2^(-rT/256)
+//             (half the nominal scale: sqrt_hot returns twice the root)
 // Two-phase evaluation for software-pipelined loops: `begin` does the range reductions of the R rows a lane owns and issues the R
 // table reads, `poly` is independent of the reads, `end` consumes them - so a loop can keep R lookups in flight.
 template <typename T> struct KappaPend { T s; T lin; int ni; T tabv; };
@@ -327,12 +330,12 @@ __device__ __forceinline__ T kappa_hot_single(T gram, T aj, const double* __rest
     return kappa_hot_end<T, KIND>(kp[0]);
 }
 
-// gradient factor from an exact squared distance in hot units (RBF: d2h = 256 d2s; Matern32: d2h = 65536 d2s)
+// gradient factor from an exact squared distance in hot units (RBF: d2h = 256 d2s; Matern32: d2h = 16384 d2s, r = 2 sqrt(d2h))
 template <typename T, int KIND, bool CLAMP, int PREC> __device__ __forceinline__ T hfac_hot_from_d2(T d2h, const double* __restrict__ tab) {
     if (KIND == CGLB_RBF) {
         return exp2_tab<CLAMP, PREC>(T(-0.5) * d2h, tab);
     } else {
-        return T(3) * exp2_tab<CLAMP, PREC>(-sqrt_pos(d2h), tab);
+        return T(3) * exp2_tab<CLAMP, PREC>(T(-2) * sqrt_pos(d2h), tab);
     }
 }
 // cooperative load of the exp2 table into LDS (call from every thread of the block, before any early exit)

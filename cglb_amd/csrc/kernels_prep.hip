@@ -20,8 +20,9 @@ __global__ __launch_bounds__(256) void prep_scaled_kernel(const T* __restrict__ 
     xa[i] = (KIND == CGLB_RBF) ? T(-0.5) * s2 : s2;
 }
 
-// hot operand set: RBF exponent -|xh_i-xh_j|^2/2 and Matern exponent -|xh_i-xh_j| are in 1/T octave (T = 2^CGLB_TAB_BITS)
-double cglb_hot_scale(const cglb_ctx* c) { return (c->kind == CGLB_RBF) ? sqrt(CGLB_HOT_UNITS) : CGLB_HOT_UNITS; }
+// hot operand set: RBF exponent -|xh_i-xh_j|^2/2 and Matern exponent -2|xh_i-xh_j| are in 1/T octave (T = 2^CGLB_TAB_BITS);
+// Matern-3/2 carries HALF the nominal scale because the hot-loop square root returns 2 sqrt (devmath.h: sqrt_hot)
+double cglb_hot_scale(const cglb_ctx* c) { return (c->kind == CGLB_RBF) ? sqrt(CGLB_HOT_UNITS) : 0.5 * CGLB_HOT_UNITS; }
 
 int launch_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out, bool hot) {
     ScaleParams sp;
