@@ -7,10 +7,9 @@
 //     x_j / a_j / p_j are wave-uniform scalar loads exactly as in the plain kernel (kernels_kff.hip);
 //   * row sums stay in the lane that owns the row (no reduction);
 //   * the column contribution sum_i kappa_ij p_i of a column j is a sum ACROSS lanes.  Columns are taken in
-//     batches of 16; the 16 per-lane partials are reduced together by a transpose-reduce (4 select/shuffle/add
-//     stages that halve the number of live vectors, then two butterfly adds): ~3 fp64-instruction equivalents
-//     per column instead of 18 for sixteen separate wave reductions; the 16 sums land in lanes 0..15 and are
-//     stored with one 128-B store;
+//     batches of 16; the 16 per-lane partials are transposed through a small LDS scratch (8 columns at a time) so that
+//     each lane adds 8 lanes of one column and three shuffles finish the sum: ~1 fp64 instruction per column and lane
+//     instead of 18 for sixteen separate wave reductions (an in-register transpose-reduce, round 1, cost ~5);
 //   * nothing is accumulated with atomics: every (slot, element) of the partial slabs is written by exactly one
 //     workgroup and the combine kernel adds the valid slots in fixed order, so results are bitwise reproducible.
 // Slab layout (element type double), n = number of rows of the square block:
@@ -33,13 +32,17 @@
 typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane side by side: v_pk_fma_f32 (fp32 path)
 
 #define SYM_CHUNK_MAX 1024  // column chunk of a work item: at most this many columns (their sums are staged in LDS)
+#ifndef CGLB_SYM_TR_REG
+#define CGLB_SYM_TR_REG 0
+#endif
+#define SYM_TR_LD 65         // leading dimension of the 8 x 64 transposition scratch of a wave (odd: the column reads spread over the banks)
 
 // One work item: rows of block `rb` against the columns of chunk `k` that lie at or right of the block's first row.  Row sums go to
 // Prow; the column sums (transposed use of the kernel values) go to `cs`, this wave's LDS array indexed by column - k * chunk.
 template <typename T, int KIND, int DP, int R, bool CLAMP, int PREC>
 __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p, const T* __restrict__ pc,
                                              int64_t row0, int64_t n, int64_t chunk, int64_t rb, int64_t k, int64_t cslot, int64_t prow_ld,
-                                             T* __restrict__ Prow, T* __restrict__ cs, const double* __restrict__ tab, int lane) {
+                                             T* __restrict__ Prow, T* __restrict__ cs, T* __restrict__ tr, const double* __restrict__ tab, int lane) {
     constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP;
     constexpr int RBROWS = 64 * R;
     const int64_t rbase = rb * RBROWS;
@@ -170,8 +173,7 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
             for (int d = 0; d < DP; ++d) xj[d] = xn[d];
         }
         if (jb >= sym_from) {  // wave-uniform
-            // transpose-reduce: after stage s the vector q holds, in lane l, the sum over the lanes that differ from l in
-            // bits 0..s, of column 2^(s+1) q + (l & (2^(s+1)-1)).
+#if CGLB_SYM_TR_REG  // round-1 form, kept for A/B builds (EXTRA_DEFS=-DCGLB_SYM_TR_REG=1): in-register transpose-reduce
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bool hi = (lane >> s) & 1;
@@ -187,6 +189,28 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             if (lane < SYM_BATCH) cs[jb - k * chunk + lane] = v;
+#else
+            // Column sums of the batch = sums ACROSS the 64 lanes of t[0..15].  Transposed through LDS, 8 columns at a time: every lane
+            // writes its 8 partials (row jj of `tr`, stride SYM_TR_LD: conflict-free), then lane (c = lane & 7, g = lane >> 3) adds
+            // the 8 lanes 8g..8g+7 of column c in fixed order and three xor-shuffles add the 8 groups: 7 + 3 adds and no selects per
+            // 32 pairs, against 83 VALU instructions per 64 pairs for the in-register transpose-reduce (4 select/shuffle/add
+            // stages) this replaces.  One wave, in-order LDS: no barrier; the wave_barrier calls only pin the compiler's order.
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) tr[jj * SYM_TR_LD + lane] = t[8 * half + jj];
+                __builtin_amdgcn_wave_barrier();
+                const T* __restrict__ src = tr + (lane & 7) * SYM_TR_LD + (lane & ~7);
+                T v = src[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) v += src[i];
+                __builtin_amdgcn_wave_barrier();
+                v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (lane < 8) cs[jb - k * chunk + 8 * half + lane] = v;
+            }
+#endif
         }
     }
     if (PACKED) {  // the packed row sums continue unpacked in the tail / are stored below
@@ -231,13 +255,14 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
 // the workgroup adds the four arrays in fixed order and stores ONE column-sum vector per (group, chunk): a quarter of the slab
 // elements, writes and combine-kernel reads of one vector per (row block, chunk).
 template <typename T, int KIND, int DP, int R, bool CLAMP, int PREC>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : (DP <= 8 ? 3 : 1))) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
                                                       const T* __restrict__ pw, const T* __restrict__ wcol,
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items,
                                                       const int2* __restrict__ groups, int rb_stride, int64_t prow_ld, T* __restrict__ Prow,
                                                       T* __restrict__ Pcol, const double* __restrict__ exp_tab) {
     __shared__ double tab[CGLB_TAB_SIZE];
     __shared__ T csum[4 * SYM_CHUNK_MAX];
+    __shared__ T trbuf[4 * 8 * SYM_TR_LD];
     load_exp_table(tab, exp_tab);  // before the early exit below: every thread reaches the barrier inside
     constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP;
     const T* __restrict__ pc = FOLD ? pw : p;  // column-side operand
@@ -253,7 +278,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 1)) void kff_sym_kernel(
     if (__builtin_amdgcn_readfirstlane(it.x) >= 0) {
         const int64_t rb = __builtin_amdgcn_readfirstlane(it.x), k = __builtin_amdgcn_readfirstlane(it.y);
         const int64_t cslot = rb / rb_stride;  // compact slot: with a cyclic rank distribution only every rb_stride-th block is here
-        kff_sym_item<T, KIND, DP, R, CLAMP, PREC>(Xs, xa, p, pc, row0, n, chunk, rb, k, cslot, prow_ld, Prow, cs, tab, lane);
+        kff_sym_item<T, KIND, DP, R, CLAMP, PREC>(Xs, xa, p, pc, row0, n, chunk, rb, k, cslot, prow_ld, Prow, cs, trbuf + wave * 8 * SYM_TR_LD, tab, lane);
     }
     __syncthreads();
     const int64_t gslot = __builtin_amdgcn_readfirstlane(grp.x), k = __builtin_amdgcn_readfirstlane(grp.y);
