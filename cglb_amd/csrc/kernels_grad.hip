@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
 // the pair value comes from the Gram chain seeded with the row norm exactly as in the mat-vec (D fma + 1 instead of D sub, D mul,
 // D add), and the per-dimension sums are built from moments,
 //   sum_j hv_ij (x_id - x_jd)^2 = x_id^2 S0_i - 2 x_id S1_id + S2_id,   S0 = sum hv, S1_d = sum hv x_jd, S2_d = sum hv x_jd^2,
-// with x_jd and x_jd^2 both wave-uniform scalar operands: 2 D + 1 accumulate instructions per pair as before, ~38 instead of 46 in all.
+// with x_jd and x_jd^2 both wave-uniform scalar operands.  S0 and S1 are per row (they are weighted by x_id afterwards); S2 enters only
+// through its sum over rows, so the R rows of a lane share ONE set of D accumulators fed with the sum of their R pair weights:
+// D + D/R + 2 accumulate instructions per pair (R = 2: ~35 in all, against 46 for direct differences).
 // The expansion cancels when |x_d| >> |x_id - x_jd| for the pairs that carry weight (lengthscale far below the data range): the
 // operands are centred, so the loss is ~log10((range / l)^2) of 16 digits - irrelevant against the 1e-8 the optimiser needs.
 template <typename T, int KIND, int DP, int R, int PREC>
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict_
     load_exp_table(tab, exp_tab);
     const int64_t rblock = ((int64_t)blockIdx.x * rb_stride + rb_offset) * (256 * R);  // cyclic over ranks when rb_stride > 1
     const int64_t rbase = rblock + threadIdx.x;
-    T xi[R][DP], S1[R][DP], S2[R][DP], S0[R], aseed[R], ui[R], vi[R];
+    T xi[R][DP], S1[R][DP], S2[DP], S0[R], aseed[R], ui[R], vi[R];  // S2 is shared by the R rows of a lane: only its sum over rows is used
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int64_t row = rbase + (int64_t)k * 256;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict_
         for (int d = 0; d < DP; ++d) {
             xi[k][d] = Xh[(row0 + rr) * DP + d];
             S1[k][d] = 0;
-            S2[k][d] = 0;
+            if (k == 0) S2[d] = 0;
         }
         S0[k] = 0;
         const T a = ah[row0 + rr];
@@ -140,26 +142,27 @@ __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict_
             earg[k] = (KIND == CGLB_RBF) ? g + aj : sqrt_hot<PREC>(tfma<T>(T(-2), g, aj));  // RBF: exponent; Matern: r (exponent -r)
         }
         exp2_tab_batch<false, KIND != CGLB_RBF, PREC, R>(earg, tab, h);
+        T cj = 0;  // sum of the R pair weights of this column: the second moment needs only that (D fma per column, not per pair)
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             T w = ui[k] * vj;
             w = tfma<T>(vi[k], wu, w);
             const T hv = h[k] * w;
             S0[k] += hv;
+            cj = (k == 0) ? hv : cj + hv;
 #pragma unroll
-            for (int d = 0; d < DP; ++d) {
-                S1[k][d] = tfma<T>(hv, xj[d], S1[k][d]);
-                S2[k][d] = tfma<T>(hv, sj[d], S2[k][d]);
-            }
+            for (int d = 0; d < DP; ++d) S1[k][d] = tfma<T>(hv, xj[d], S1[k][d]);
         }
+#pragma unroll
+        for (int d = 0; d < DP; ++d) S2[d] = tfma<T>(cj, sj[d], S2[d]);
     }
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
-        double s = 0.0;
+        double s = (double)S2[d];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const double x = (double)xi[k][d];
-            s += x * (x * (double)S0[k] - 2.0 * (double)S1[k][d]) + (double)S2[k][d];
+            s += x * (x * (double)S0[k] - 2.0 * (double)S1[k][d]);
         }
         s = block_sum(s, smem);
         if (threadIdx.x == 0) part[(blk0 + (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * DP + d] = s;
@@ -205,6 +208,11 @@ static int ensure_gpart(cglb_ctx* c, size_t need) {
     return CGLB_OK;
 }
 
+// rows per lane of the Gram-form kernel when D <= 8 (4 rows - 204 VGPRs, 2 waves per SIMD - measured 6.28 ms against 5.55 ms)
+#ifndef CGLB_GRAM_ROWS
+#define CGLB_GRAM_ROWS 2
+#endif
+
 static inline double kscale_of(const cglb_ctx* c) { return (c->kind == CGLB_RBF) ? sqrt(CGLB_LOG2E) : CGLB_SQRT3 * CGLB_LOG2E; }
 
 // out_dl[d] (device double[D], overwritten) = sum_{i local, j} u_i dK_ij/dl_d v_j
@@ -219,14 +227,17 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
         HIP_CHECK(c, hipMemsetAsync(out_dl, 0, sizeof(double) * c->D, c->stream));
         return CGLB_OK;
     }
+    const bool use_gram = c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64;  // fp32 keeps direct differences: no digits to spare
     const int R = c->Dp <= 8 ? 2 : 1;
-    const int64_t bx = (c->nloc + 256 * R - 1) / (256 * R);
+    const int Rg = c->Dp <= 8 ? CGLB_GRAM_ROWS : 1;  // the Gram-form kernel (square range only)
     // three column ranges: the square block (symmetric form) and the shard's off-diagonal ranges [0,r0), [r1,N)
     struct Range { int64_t col0, ncols; bool sym; int64_t jsplit, jchunk; } rg[3] = {
         {c->r0, c->nloc, true, 0, 0}, {0, c->r0, false, 0, 0}, {c->r1, c->N - c->r1, false, 0, 0}};
     int64_t nblk = 0;
     for (auto& r : rg) {
         if (r.ncols <= 0) continue;
+        const int rr = (r.sym && use_gram) ? Rg : R;
+        const int64_t bx = (c->nloc + 256 * rr - 1) / (256 * rr);
         int64_t js = (8192 + bx - 1) / bx;
         if (r.sym) js *= 2;  // about half of the (row block, chunk) cells of the square are left of the diagonal and exit at once
         if (js > 1024) js = 1024;
@@ -240,6 +251,8 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
     int64_t blk0 = 0;
     for (auto& r : rg) {
         if (r.ncols <= 0) continue;
+        const int rr = (r.sym && use_gram) ? Rg : R;
+        const int64_t bx = (c->nloc + 256 * rr - 1) / (256 * rr);
         dim3 grid((unsigned)bx, (unsigned)r.jsplit);
 #define GK_LAUNCH(RR, SYMV)                                                                                                        \
     hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, SYMV, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh + c->r0 * DP,        \
@@ -249,9 +262,9 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
     hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,     \
                        (const T*)c->xah, (const T*)u_local - c->r0, (const T*)v_full, c->r0, c->nloc, r.jchunk, blk0, 1, 0, c->gpart,     \
                        (const double*)c->exp_tab)
-        if (r.sym && c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64) {  // fp32 keeps direct differences: no digits to spare
+        if (r.sym && use_gram) {
             // u_local is indexed by global row inside the kernel (row0 + local), hence the shifted base pointer
-            CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GG_LAUNCH(2); } else { GG_LAUNCH(1); }));
+            CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GG_LAUNCH(CGLB_GRAM_ROWS); } else { GG_LAUNCH(1); }));
         } else if (r.sym) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); })); }
         else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); })); }
 #undef GG_LAUNCH
@@ -274,7 +287,8 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
         sp.center[d] = 0;
         sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
     }
-    const int R = c->Dp <= 8 ? 2 : 1;
+    const bool use_gram = c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64;
+    const int R = c->Dp <= 8 ? (use_gram ? CGLB_GRAM_ROWS : 2) : 1;
     const int64_t nb = (c->N + 256 * R - 1) / (256 * R);
     const int64_t bx = c->par_rank < nb ? (nb - c->par_rank + c->par_world - 1) / c->par_world : 0;
     if (bx == 0) {
@@ -298,7 +312,7 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
     hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,    \
                        (const T*)c->xah, (const T*)u_full, (const T*)v_full, (int64_t)0, c->N, jchunk, (int64_t)0, c->par_world, c->par_rank, \
                        c->gpart, (const double*)c->exp_tab)
-    if (c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GGC_LAUNCH(2); } else { GGC_LAUNCH(1); })); }
+    if (use_gram) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GGC_LAUNCH(CGLB_GRAM_ROWS); } else { GGC_LAUNCH(1); })); }
     else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); })); }
 #undef GGC_LAUNCH
 #undef GKC_LAUNCH
