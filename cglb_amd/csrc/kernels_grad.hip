@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void grad_panel_kernel(const T* __restrict__ G
 #pragma unroll
     for (int d = 0; d < DP; ++d) { adl[d] = 0.0; adz[d] = 0.0; }
     for (int64_t n = n0 + threadIdx.x; n < n1; n += blockDim.x) {
-        T g = G[(int64_t)m * ldg + n];
+        T g = CGLB_STREAM_LOAD(G + (int64_t)m * ldg + n);
         if (cvec) g = tfma<T>(cm, wvec[n], g);
         T df[DP], d2 = 0;
 #pragma unroll

@@ -318,9 +318,9 @@ __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restric
             int64_t k = k0 + g;
             for (; k + 28 < nchunk; k += 32) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] += Prow[(k + 4 * u) * prow_ld + li];
+                for (int u = 0; u < 8; ++u) a[u] += CGLB_STREAM_LOAD(Prow + (k + 4 * u) * prow_ld + li);
             }
-            for (int u = 0; k < nchunk; k += 4, ++u) a[u] += Prow[k * prow_ld + li];
+            for (int u = 0; k < nchunk; k += 4, ++u) a[u] += CGLB_STREAM_LOAD(Prow + k * prow_ld + li);
         }
         {
             // this rank's row blocks before block rbi contributed to column i; they are stored four to a slot (one per workgroup)
@@ -329,9 +329,9 @@ __global__ __launch_bounds__(256) void kff_sym_combine_kernel(const T* __restric
             int64_t c = g;
             for (; c + 28 < ns; c += 32) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] += Pcol[(c + 4 * u) * n + i];
+                for (int u = 0; u < 8; ++u) a[u] += CGLB_STREAM_LOAD(Pcol + (c + 4 * u) * n + i);
             }
-            for (int u = 0; c < ns; c += 4, ++u) a[u] += Pcol[c * n + i];
+            for (int u = 0; c < ns; c += 4, ++u) a[u] += CGLB_STREAM_LOAD(Pcol + c * n + i);
         }
     }
     gsum[g][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));

@@ -185,6 +185,8 @@ int launch_sub_scalar(cglb_ctx* c, void* out, const void* y_local, double mean, 
 // One load of r serves GU_ROWS panel rows (with one row per block r was re-read from L2 once per panel row: as many L2 bytes as
 // HBM bytes) and GU_ROWS independent 16-B panel loads are in flight per thread.
 #define GU_ROWS 4
+typedef double gu_d2 __attribute__((ext_vector_type(2)));  // native vectors: accepted by the non-temporal load builtin
+typedef float gu_f4 __attribute__((ext_vector_type(4)));
 template <typename T>
 __global__ __launch_bounds__(256) void gemv_u_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ r, int64_t nloc, int M,
                                                      int64_t chunk, double* __restrict__ upart, T* __restrict__ u_direct) {
@@ -203,12 +205,12 @@ __global__ __launch_bounds__(256) void gemv_u_kernel(const T* __restrict__ A, in
     // vector body when the row starts are 16-B aligned (lda is a multiple of 8 elements)
     const bool aligned = ((((uintptr_t)(row[0] + n0)) | ((uintptr_t)(r + n0)) | (uintptr_t)(lda * sizeof(T))) & 15) == 0;
     if (aligned) {
-        using VT = typename std::conditional<sizeof(T) == 8, double2, float4>::type;
+        using VT = typename std::conditional<sizeof(T) == 8, gu_d2, gu_f4>::type;
         for (; i + V <= n1; i += (int64_t)blockDim.x * V) {
             const VT b = *reinterpret_cast<const VT*>(r + i);
             VT a[GU_ROWS];
 #pragma unroll
-            for (int q = 0; q < GU_ROWS; ++q) a[q] = *reinterpret_cast<const VT*>(row[q] + i);
+            for (int q = 0; q < GU_ROWS; ++q) a[q] = CGLB_STREAM_LOAD(reinterpret_cast<const VT*>(row[q] + i));
 #pragma unroll
             for (int q = 0; q < GU_ROWS; ++q) {
                 if constexpr (sizeof(T) == 8) {
@@ -343,10 +345,10 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(const T* __restrict__ A, in
     T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int m = m0;
     for (; m + 4 <= m1; m += 4) {
-        s0 = tfma<T>(A[(int64_t)m * lda + n], t[m], s0);
-        s1 = tfma<T>(A[(int64_t)(m + 1) * lda + n], t[m + 1], s1);
-        s2 = tfma<T>(A[(int64_t)(m + 2) * lda + n], t[m + 2], s2);
-        s3 = tfma<T>(A[(int64_t)(m + 3) * lda + n], t[m + 3], s3);
+        s0 = tfma<T>(CGLB_STREAM_LOAD(A + (int64_t)m * lda + n), t[m], s0);
+        s1 = tfma<T>(CGLB_STREAM_LOAD(A + (int64_t)(m + 1) * lda + n), t[m + 1], s1);
+        s2 = tfma<T>(CGLB_STREAM_LOAD(A + (int64_t)(m + 2) * lda + n), t[m + 2], s2);
+        s3 = tfma<T>(CGLB_STREAM_LOAD(A + (int64_t)(m + 3) * lda + n), t[m + 3], s3);
     }
     for (; m < m1; ++m) s0 = tfma<T>(A[(int64_t)m * lda + n], t[m], s0);
     tpart[(int64_t)blockIdx.y * nloc + n] = (s0 + s1) + (s2 + s3);
