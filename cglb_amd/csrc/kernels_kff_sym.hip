@@ -255,7 +255,9 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
 // the workgroup adds the four arrays in fixed order and stores ONE column-sum vector per (group, chunk): a quarter of the slab
 // elements, writes and combine-kernel reads of one vector per (row block, chunk).
 template <typename T, int KIND, int DP, int R, bool CLAMP, int PREC>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : (DP <= 8 ? 3 : 1))) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
+// waves per SIMD: fp32 4 (at D = 16 that costs a 184-byte spill and is still faster than 3 waves without: 203 vs 235 ms per mat-vec at
+// N = 1M); fp64 3 for the 4-rows-per-lane instances (D = 5..8: 160-167 VGPRs), unconstrained for 8 rows per lane (D <= 4) and D > 8
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : ((DP <= 8 && R <= 4) ? 3 : 1))) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
                                                       const T* __restrict__ pw, const T* __restrict__ wcol,
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items,
                                                       const int2* __restrict__ groups, int rb_stride, int64_t prow_ld, T* __restrict__ Prow,
