@@ -84,11 +84,12 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
 // the pair value comes from the Gram chain seeded with the row norm exactly as in the mat-vec (D fma + 1 instead of D sub, D mul,
 // D add), and the per-dimension sums are built from moments,
 //   sum_j hv_ij (x_id - x_jd)^2 = x_id^2 S0_i - 2 x_id S1_id + S2_id,   S0 = sum hv, S1_d = sum hv x_jd, S2_d = sum hv x_jd^2,
-// with x_jd and x_jd^2 both wave-uniform scalar operands.  S0 and S1 are per row (they are weighted by x_id afterwards); S2 enters only
-// through its sum over rows, so the R rows of a lane share ONE set of D accumulators fed with the sum of their R pair weights:
-// D + D/R + 2 accumulate instructions per pair (R = 2: ~35 in all, against 46 for direct differences).
+// with x_jd a wave-uniform scalar operand.  S0 and S1 are per row (they are weighted by x_id afterwards); S2 enters only through its sum
+// over rows, i.e. through the column sums of the pair weights, which are formed 8 columns at a time by a transposition through LDS (below):
+// D + 2 accumulate instructions per pair and ~1 for the transposition (D = 8: ~31 in all, against 46 for direct differences).
 // The expansion cancels when |x_d| >> |x_id - x_jd| for the pairs that carry weight (lengthscale far below the data range): the
 // operands are centred, so the loss is ~log10((range / l)^2) of 16 digits - irrelevant against the 1e-8 the optimiser needs.
+#define GRAD_TR_LD 65  // leading dimension of a wave's 8 x 64 transposition scratch (odd: the column reads spread over the banks)
 template <typename T, int KIND, int DP, int R, int PREC>
 __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict__ Xh, const T* __restrict__ Xhsq, const T* __restrict__ ah,
                                                             const T* __restrict__ u, const T* __restrict__ v, int64_t row0, int64_t n,
@@ -99,7 +100,16 @@ __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict_
     load_exp_table(tab, exp_tab);
     const int64_t rblock = ((int64_t)blockIdx.x * rb_stride + rb_offset) * (256 * R);  // cyclic over ranks when rb_stride > 1
     const int64_t rbase = rblock + threadIdx.x;
-    T xi[R][DP], S1[R][DP], S2[DP], S0[R], aseed[R], ui[R], vi[R];  // S2 is shared by the R rows of a lane: only its sum over rows is used
+    __shared__ T trbuf[4 * 8 * GRAD_TR_LD];
+    T* __restrict__ tr = trbuf + (threadIdx.x >> 6) * (8 * GRAD_TR_LD);
+    const int lane = threadIdx.x & 63;
+    // second moments: through column sums (COLSUM, below) or, for D <= 4 where that costs more than it saves, per lane with the R rows
+    // sharing one accumulator set (S2 enters only through its sum over rows)
+    constexpr bool COLSUM = DP > 4;
+    constexpr int NQ = COLSUM ? (DP + 7) / 8 : DP;  // COLSUM: dimensions (lane >> 3) + 8 q of column (lane & 7) of a batch; else S2[d]
+    T xi[R][DP], S1[R][DP], G2[NQ], S0[R], aseed[R], ui[R], vi[R];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) G2[q] = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int64_t row = rbase + (int64_t)k * 256;
@@ -108,7 +118,6 @@ __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict_
         for (int d = 0; d < DP; ++d) {
             xi[k][d] = Xh[(row0 + rr) * DP + d];
             S1[k][d] = 0;
-            if (k == 0) S2[d] = 0;
         }
         S0[k] = 0;
         const T a = ah[row0 + rr];
@@ -122,43 +131,75 @@ __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict_
     const int64_t j1 = (j0 + jchunk < n) ? j0 + jchunk : n;
     const int64_t sym_from = rblock + 256 * R;
     if (j0 < rblock) j0 = rblock;
-    for (int64_t jc = j0; jc < j1; ++jc) {
-        const int64_t j = row0 + jc;
-        const T vj = v[j];
-        const T wu = (jc >= sym_from) ? u[j] : T(0);  // wave-uniform
-        const T aj = ah[j];
-        T xj[DP], sj[DP];
+    for (int64_t jb = j0; jb < j1; jb += 8) {
+        T t[8];  // per column of the batch: the sum of this lane's R pair weights
 #pragma unroll
-        for (int d = 0; d < DP; ++d) {
-            xj[d] = Xh[j * DP + d];
-            sj[d] = Xhsq[j * DP + d];
+        for (int jj = 0; jj < 8; ++jj) {
+            const int64_t jc = jb + jj;
+            t[jj] = 0;
+            if (jc < j1) {  // wave-uniform: only the last batch of a chunk is short
+                const int64_t j = row0 + jc;
+                const T vj = v[j];
+                const T wu = (jc >= sym_from) ? u[j] : T(0);  // wave-uniform
+                const T aj = ah[j];
+                T xj[DP];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) xj[d] = Xh[j * DP + d];
+                T earg[R], h[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    T g = aseed[k];
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) g = tfma<T>(xi[k][d], xj[d], g);
+                    earg[k] = (KIND == CGLB_RBF) ? g + aj : sqrt_hot<PREC>(tfma<T>(T(-2), g, aj));  // RBF: exponent; Matern: r (exponent -r)
+                }
+                exp2_tab_batch<false, KIND != CGLB_RBF, PREC, R>(earg, tab, h);
+                T cj = 0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    T w = ui[k] * vj;
+                    w = tfma<T>(vi[k], wu, w);
+                    const T hv = h[k] * w;
+                    S0[k] += hv;
+                    cj = (k == 0) ? hv : cj + hv;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) S1[k][d] = tfma<T>(hv, xj[d], S1[k][d]);
+                }
+                t[jj] = cj;
+                if constexpr (!COLSUM) {
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) G2[d] = tfma<T>(cj, Xhsq[j * DP + d], G2[d]);
+                }
+            }
         }
-        T earg[R], h[R];
+        if constexpr (!COLSUM) continue;
+        // Second moments.  sum_ij hv_ij x_jd^2 = sum_j x_jd^2 (sum_i hv_ij): only the COLUMN sums of the pair weights are needed,
+        // so the per-pair accumulation S2_d += hv x_jd^2 (D fma per pair and D more scalar operands per column - at D = 24 / 32 they
+        // no longer fit the SGPR file: 64 v_readlane/v_writelane per column, a 3.8x slower kernel) is replaced by one transposition
+        // of the 8 partials through LDS per batch (as in the symmetric mat-vec: lane (c, g) adds 8 lanes of column c, three
+        // xor-shuffles finish the wave's column sum) and NQ fma per lane: lane (c, g) weights x_{jb+c, d}^2 for d = g, g + 8, ...
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            T g = aseed[k];
+        for (int jj = 0; jj < 8; ++jj) tr[jj * GRAD_TR_LD + lane] = t[jj];
+        __builtin_amdgcn_wave_barrier();
+        const T* __restrict__ src = tr + (lane & 7) * GRAD_TR_LD + (lane & ~7);
+        T cs = src[0];
 #pragma unroll
-            for (int d = 0; d < DP; ++d) g = tfma<T>(xi[k][d], xj[d], g);
-            earg[k] = (KIND == CGLB_RBF) ? g + aj : sqrt_hot<PREC>(tfma<T>(T(-2), g, aj));  // RBF: exponent; Matern: r (exponent -r)
+        for (int i = 1; i < 8; ++i) cs += src[i];
+        __builtin_amdgcn_wave_barrier();
+        cs += __shfl_xor(cs, 8, 64);
+        cs += __shfl_xor(cs, 16, 64);
+        cs += __shfl_xor(cs, 32, 64);
+        const int64_t jcol = jb + (lane & 7);
+        const T* __restrict__ sq = Xhsq + (row0 + (jcol < j1 ? jcol : j1 - 1)) * DP;  // columns past the chunk carry cs == 0
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int d = (lane >> 3) + 8 * q;
+            if (d < DP) G2[q] = tfma<T>(cs, sq[d], G2[q]);
         }
-        exp2_tab_batch<false, KIND != CGLB_RBF, PREC, R>(earg, tab, h);
-        T cj = 0;  // sum of the R pair weights of this column: the second moment needs only that (D fma per column, not per pair)
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            T w = ui[k] * vj;
-            w = tfma<T>(vi[k], wu, w);
-            const T hv = h[k] * w;
-            S0[k] += hv;
-            cj = (k == 0) ? hv : cj + hv;
-#pragma unroll
-            for (int d = 0; d < DP; ++d) S1[k][d] = tfma<T>(hv, xj[d], S1[k][d]);
-        }
-#pragma unroll
-        for (int d = 0; d < DP; ++d) S2[d] = tfma<T>(cj, sj[d], S2[d]);
     }
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
-        double s = (double)S2[d];
+        double s = COLSUM ? (((lane >> 3) == (d & 7)) ? (double)G2[d >> 3] : 0.0) : (double)G2[COLSUM ? 0 : d];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const double x = (double)xi[k][d];

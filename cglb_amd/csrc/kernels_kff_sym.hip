@@ -35,6 +35,9 @@ typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane
 #ifndef CGLB_SYM_TR_REG
 #define CGLB_SYM_TR_REG 0
 #endif
+#ifndef CGLB_SYM_LATE_DP
+#define CGLB_SYM_LATE_DP 24  // padded row width from which the column operands are fetched after the Gram chain (below)
+#endif
 #define SYM_TR_LD 65         // leading dimension of the 8 x 64 transposition scratch of a wave (odd: the column reads spread over the banks)
 
 // One work item: rows of block `rb` against the columns of chunk `k` that lie at or right of the block's first row.  Row sums go to
@@ -101,16 +104,20 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
         T t[SYM_BATCH];
 #pragma unroll
         for (int jj = 0; jj < SYM_BATCH; ++jj) {
-            // prefetch the next column
+            // prefetch the next column.  D <= 16: before the Gram chain (a whole column ahead).  Wider rows: AFTER the chain, into the
+            // registers its operands just left - two columns of operands (4 DP SGPRs) do not fit the scalar register file, and the
+            // compiler then parks them in VGPR lanes (D = 32: 581 spilled SGPRs, 70 v_readlane/v_writelane per column: 6.4 ms for a
+            // mat-vec at N = 60k that takes 3.2 without); the loads then have the 2^x and the accumulation of the column to land.
+            constexpr bool LATE = DP >= CGLB_SYM_LATE_DP;
             T xn[DP], an = T(0), pn;
-            {
-                const int64_t o = (jj + 1 < SYM_BATCH) ? jj + 1 : nb;
+            const int64_t o = (jj + 1 < SYM_BATCH) ? jj + 1 : nb;
+            if (!LATE) {
                 if (!FOLD) an = xaj[o];
                 pn = pjv[o];
 #pragma unroll
                 for (int d = 0; d < DP; ++d) xn[d] = xsj[o * DP + d];
+                __builtin_amdgcn_sched_barrier(0);  // issue the prefetch first; it is consumed a whole column later
             }
-            __builtin_amdgcn_sched_barrier(0);  // issue the prefetch first; it is consumed a whole column later
             T gram[R];
             if (PACKED) {
 #pragma unroll
@@ -129,6 +136,14 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
                     for (int d = 0; d < DP; ++d) g = tfma<T>(xi[r % RU][d], xj[d], g);
                     gram[r] = g;
                 }
+            }
+            if (LATE) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (!FOLD) an = xaj[o];
+                pn = pjv[o];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) xn[d] = xsj[o * DP + d];
+                __builtin_amdgcn_sched_barrier(0);
             }
             KappaPend<T> kp[R];
             kappa_hot_begin_batch<T, KIND, CLAMP, FOLD, PREC, R>(gram, aj, tab, kp);
@@ -173,7 +188,9 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
             for (int d = 0; d < DP; ++d) xj[d] = xn[d];
         }
         if (jb >= sym_from) {  // wave-uniform
-#if CGLB_SYM_TR_REG  // round-1 form, kept for A/B builds (EXTRA_DEFS=-DCGLB_SYM_TR_REG=1): in-register transpose-reduce
+            // R == 1 (D > 16): the in-register transpose-reduce of round 1 - those instances run 4 waves per SIMD, which the LDS
+            // scratch of the other form would cut to 3 (D = 24: 2.57 -> 2.91 ms).  Also for A/B builds (EXTRA_DEFS=-DCGLB_SYM_TR_REG=1).
+            if constexpr (R == 1 || CGLB_SYM_TR_REG) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bool hi = (lane >> s) & 1;
@@ -189,7 +206,7 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             if (lane < SYM_BATCH) cs[jb - k * chunk + lane] = v;
-#else
+            } else {
             // Column sums of the batch = sums ACROSS the 64 lanes of t[0..15].  Transposed through LDS, 8 columns at a time: every lane
             // writes its 8 partials (row jj of `tr`, stride SYM_TR_LD: conflict-free), then lane (c = lane & 7, g = lane >> 3) adds
             // the 8 lanes 8g..8g+7 of column c in fixed order and three xor-shuffles add the 8 groups: 7 + 3 adds and no selects per
@@ -210,7 +227,7 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
                 v += __shfl_xor(v, 32, 64);
                 if (lane < 8) cs[jb - k * chunk + 8 * half + lane] = v;
             }
-#endif
+            }
         }
     }
     if (PACKED) {  // the packed row sums continue unpacked in the tail / are stored below
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : ((DP <= 8 && R <= 4) ? 3
                                                       T* __restrict__ Pcol, const double* __restrict__ exp_tab) {
     __shared__ double tab[CGLB_TAB_SIZE];
     __shared__ T csum[4 * SYM_CHUNK_MAX];
-    __shared__ T trbuf[4 * 8 * SYM_TR_LD];
+    __shared__ T trbuf[(R == 1 || CGLB_SYM_TR_REG) ? 1 : 4 * 8 * SYM_TR_LD];  // transposition scratch of the four waves (unused for R == 1)
     load_exp_table(tab, exp_tab);  // before the early exit below: every thread reaches the barrier inside
     constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP;
     const T* __restrict__ pc = FOLD ? pw : p;  // column-side operand
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : ((DP <= 8 && R <= 4) ? 3
     if (__builtin_amdgcn_readfirstlane(it.x) >= 0) {
         const int64_t rb = __builtin_amdgcn_readfirstlane(it.x), k = __builtin_amdgcn_readfirstlane(it.y);
         const int64_t cslot = rb / rb_stride;  // compact slot: with a cyclic rank distribution only every rb_stride-th block is here
-        kff_sym_item<T, KIND, DP, R, CLAMP, PREC>(Xs, xa, p, pc, row0, n, chunk, rb, k, cslot, prow_ld, Prow, cs, trbuf + wave * 8 * SYM_TR_LD, tab, lane);
+        kff_sym_item<T, KIND, DP, R, CLAMP, PREC>(Xs, xa, p, pc, row0, n, chunk, rb, k, cslot, prow_ld, Prow, cs, trbuf + ((R == 1 || CGLB_SYM_TR_REG) ? 0 : wave * 8 * SYM_TR_LD), tab, lane);
     }
     __syncthreads();
     const int64_t gslot = __builtin_amdgcn_readfirstlane(grp.x), k = __builtin_amdgcn_readfirstlane(grp.y);
