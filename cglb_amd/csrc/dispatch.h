@@ -14,7 +14,9 @@
         case 8: { constexpr int DP = 8; __VA_ARGS__; } break;               \
         case 12: { constexpr int DP = 12; __VA_ARGS__; } break;             \
         case 16: { constexpr int DP = 16; __VA_ARGS__; } break;             \
+        case 20: { constexpr int DP = 20; __VA_ARGS__; } break;             \
         case 24: { constexpr int DP = 24; __VA_ARGS__; } break;             \
+        case 28: { constexpr int DP = 28; __VA_ARGS__; } break;             \
         case 32: { constexpr int DP = 32; __VA_ARGS__; } break;             \
         default: return cglb_fail(c, CGLB_ERR_BAD_ARG, "unsupported padded dimension"); \
     }
