@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import json
 import os
+from contextlib import contextmanager
 from dataclasses import asdict
 from functools import singledispatch
 from pathlib import Path
@@ -193,8 +194,39 @@ def _create_model_cglb(model_cfg: CGLBConfig, data: Data):
     return CGLB((np.asarray(data[0]), np.asarray(data[1]).reshape(-1)), likelihood, kernel, dtype=_STATE["dtype"], **extra)
 
 
+@contextmanager
+def _narrow_host_pools():
+    """The optimiser's host side is a handful of small vectors (M D + D + 3 numbers), all heavy work runs on the GPU.  With their default
+    widths (one thread per visible core: 128 on a box that grants this process 16) the OpenMP / BLAS pools of torch and numpy spin between
+    calls and starve the HIP runtime's own threads: at N = 57k, D = 27 kernel launches stalled for ~70 ms at a time and an evaluation took
+    99 ms of wall time for 58 ms of GPU work (47 ms with narrow pools).  CGLB_HOST_THREADS overrides the width (default 4; 0 = leave alone)."""
+    n = int(os.environ.get("CGLB_HOST_THREADS", "4"))
+    if n <= 0:
+        yield
+        return
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(prev, n))
+    try:
+        try:
+            from threadpoolctl import threadpool_limits
+        except Exception:  # pragma: no cover
+            threadpool_limits = None
+        if threadpool_limits is None:
+            yield
+        else:
+            with threadpool_limits(limits=n):
+                yield
+    finally:
+        torch.set_num_threads(prev)
+
+
 @optimize.register
 def _optimize_cglb(model: CGLB, dataset, num_steps: int, logger: Logger, optimize: str = "scipy"):
+    with _narrow_host_pools():
+        return _optimize_cglb_impl(model, dataset, num_steps, logger, optimize)
+
+
+def _optimize_cglb_impl(model: CGLB, dataset, num_steps: int, logger: Logger, optimize: str = "scipy"):
     """interface.py:445-543: warm-up evaluation outside the clock, then up to four L-BFGS-B rounds, the last two
     without the inducing points."""
     assert optimize == "scipy"
