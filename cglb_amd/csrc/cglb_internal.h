@@ -135,7 +135,7 @@ static inline int cglb_fail(cglb_ctx* ctx, int code, const std::string& msg) {
 }
 
 static inline int pad_dim(int d) {
-    const int sizes[] = {1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 32};  // 20 and 28: the reference's own data sets have D = 17, 18, 26, 27
+    const int sizes[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 28, 32};  // 10, 20 and 28: the reference's own data sets have D = 9, 17, 18, 26, 27
     for (int s : sizes)
         if (d <= s) return s;
     return -1;

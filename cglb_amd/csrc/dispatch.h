@@ -12,6 +12,7 @@
         case 4: { constexpr int DP = 4; __VA_ARGS__; } break;               \
         case 6: { constexpr int DP = 6; __VA_ARGS__; } break;               \
         case 8: { constexpr int DP = 8; __VA_ARGS__; } break;               \
+        case 10: { constexpr int DP = 10; __VA_ARGS__; } break;             \
         case 12: { constexpr int DP = 12; __VA_ARGS__; } break;             \
         case 16: { constexpr int DP = 16; __VA_ARGS__; } break;             \
         case 20: { constexpr int DP = 20; __VA_ARGS__; } break;             \

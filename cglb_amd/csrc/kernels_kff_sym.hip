@@ -35,6 +35,9 @@ typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane
 #ifndef CGLB_SYM_TR_REG
 #define CGLB_SYM_TR_REG 0
 #endif
+#ifndef CGLB_SYM_R4_MAX_DP
+#define CGLB_SYM_R4_MAX_DP 12  // widest padded row that still gets 4 rows per lane in fp64 (DP = 12: 3.67 -> 3.40 ms at N = 100k against 2 rows)
+#endif
 #ifndef CGLB_SYM_LATE_DP
 #define CGLB_SYM_LATE_DP 24  // padded row width from which the column operands are fetched after the Gram chain (below)
 #endif
@@ -484,7 +487,7 @@ static int ensure_sym_items(cglb_ctx* c, int64_t n, int rbrows, int64_t chunk, i
 template <typename T, int KIND, int DP>
 static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* pdot_slot, bool cyclic) {
     // rows per lane: bounded by the VGPR budget (R * DP operands of sizeof(T)); fp32 operands are half the size
-    constexpr int R = sizeof(T) == 8 ? ((DP <= 4) ? 8 : (DP <= 8) ? 4 : (DP <= 16 ? 2 : 1)) : ((DP <= 4) ? 8 : (DP <= 16) ? 4 : 2);
+    constexpr int R = sizeof(T) == 8 ? ((DP <= 4) ? 8 : (DP <= CGLB_SYM_R4_MAX_DP) ? 4 : (DP <= 16 ? 2 : 1)) : ((DP <= 4) ? 8 : (DP <= 16) ? 4 : 2);
     constexpr int RBROWS = 64 * R;
     const int64_t n = cyclic ? c->N : c->nloc;
     const int64_t row0 = cyclic ? 0 : c->r0;

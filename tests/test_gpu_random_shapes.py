@@ -40,7 +40,9 @@ def test_random_shape_matches_oracle(case):
     assert abs(res.steps - ref.steps) <= 1, info
     assert res.bound == pytest.approx(refg.bound, rel=1e-9), info
     if res.steps == ref.steps:
-        assert res.bound == pytest.approx(ref.bound, rel=1e-6), info                            # the north_star tolerance
+        # the north_star tolerance; beyond a restart (40 steps) two correct solves have drifted apart by round-off and agree only to a
+        # fraction of the stopping tolerance itself (the bound moves by 1/2 r^T P r <= max_error between admissible stopping points)
+        assert res.bound == pytest.approx(ref.bound, rel=1e-6, abs=(0.5 * tol if res.steps > 40 else 0.0)), info
     for key in ("lengthscales", "Z"):
         # relative to the largest entry, with a floor tied to the bound: with M = N (inducing points on every datum, K_uu as ill
         # conditioned as K_ff) the whole Z gradient is ~1e-11 of the bound and carries cond(K_uu) * eps of absolute error on both sides
