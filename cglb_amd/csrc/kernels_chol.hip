@@ -4,7 +4,7 @@
 // ROLLED loops on purpose: a one-wave, fully unrolled factorisation of the 64 x 64 block (rows in registers, operands by
 // v_readlane or LDS broadcast) is 50-60 KB of straight-line code that runs once on a cold instruction cache, and measured
 // 38 us (readlane form) / 90 us (LDS form) - the time of fetching the instructions, not of executing them.
-//   diag    64 x 64 diagonal block, 1024 threads: lane = row, wave = column group; one barrier per column
+//   diag    64 x 64 diagonal block, 512 threads: lane = row, wave = column group; one barrier per column
 //   panel   rows below it, one wave per row (lane = column), the finished entry broadcast with v_readlane (no barrier)
 //   update  trailing rank-64 update A22 -= P P^T, one 64 x 64 tile of the lower triangle per workgroup
 //           (rocBLAS syrk splits this shape into a diagonal kernel and 5-7 small GEMMs: ~45 us of launches per step).
@@ -43,8 +43,8 @@ __device__ __forceinline__ double pivot_rcp(double s) {
 }
 __device__ __forceinline__ float pivot_rcp(float s) { return 1.0f / s; }
 
-// Factor the nb x nb diagonal block at (k0, k0).  Thread (r = lane, w = wave) holds A[r][w + 16 k], k = 0..3, in four registers.
-// Step j (column j = 16 jq + jj lives in wave jj, register jq): the owning wave puts the column as it stands ("raw":
+// Factor the nb x nb diagonal block at (k0, k0).  Thread (r = lane, w = wave) holds A[r][w + NW k], k = 0..NC-1, in NC registers
+// (NW = 8 waves, NC = 8 columns).  Step j (column j = NW jq + jj lives in wave jj, register jq): the owning wave puts the column as it stands ("raw":
 // a_rj after the updates of columns < j) into LDS; after ONE barrier every thread reads the pivot p = a_jj, its row entry a_rj
 // and the entries a_cj of its own columns c > j, and applies a_rc -= (a_rj a_cj) / p  (= L_rj L_cj).  The square roots are
 // taken after the loop (L_rj = a_rj / sqrt(p_j) from the raw columns kept in the registers and the pivots kept in LDS), so that
@@ -54,26 +54,30 @@ __device__ __forceinline__ float pivot_rcp(float s) { return 1.0f / s; }
 // A short block (nb < 64, last block of a ragged matrix) is padded with the identity.  info[0] receives k0 + j + 1 for the
 // first non-positive pivot (only if still 0); the block is then left unwritten.  Dblk receives a dense transposed copy of the
 // factored block (Dblk[t * 64 + c] = L[c][t] for c > t, zero elsewhere) plus the reciprocal diagonal for the panel kernel.
+#ifndef CHOL_DIAG_WAVES
+#define CHOL_DIAG_WAVES 8  // waves of the diagonal-block kernel: each thread holds 64 / waves columns of its row (16 / 8 / 4 waves: 792 / 730 / 808 us per 1024^2 factorisation - the per-column work every wave repeats competes for issue slots with the updates)
+#endif
 template <typename T>
-__global__ __launch_bounds__(1024) void chol_diag_kernel(T* __restrict__ A, int n, int k0, int nb, int* __restrict__ info,
+__global__ __launch_bounds__(64 * CHOL_DIAG_WAVES) void chol_diag_kernel(T* __restrict__ A, int n, int k0, int nb, int* __restrict__ info,
                                                          T* __restrict__ Dblk) {
     __shared__ T colraw[2][CHOL_NB];
     __shared__ T pivs[CHOL_NB];
     const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
-    T a[4];
+    constexpr int NW = CHOL_DIAG_WAVES, NC = CHOL_NB / NW;  // waves, columns per thread
+    T a[NC];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int cc = w + 16 * k;
+    for (int k = 0; k < NC; ++k) {
+        const int cc = w + NW * k;
         T v = (cc == r) ? T(1) : T(0);  // identity padding
         if (r < nb && cc < nb) v = (cc <= r) ? A[(size_t)(k0 + cc) * n + k0 + r] : T(0);
         a[k] = v;
     }
     int bad = 0;
 #pragma unroll
-    for (int jq = 0; jq < 4; ++jq) {
+    for (int jq = 0; jq < NC; ++jq) {
 #pragma unroll 1
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = 16 * jq + jj;
+        for (int jj = 0; jj < NW; ++jj) {
+            const int j = NW * jq + jj;
             T* buf = colraw[j & 1];
             if (w == jj) buf[r] = a[jq];
             __syncthreads();
@@ -84,9 +88,9 @@ __global__ __launch_bounds__(1024) void chol_diag_kernel(T* __restrict__ A, int 
             if (threadIdx.x == 0) pivs[j] = ok ? piv : T(1);
             const T rp = pivot_rcp(ok ? piv : T(1));
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NC; ++k) {
                 if (k < jq) continue;
-                const T upd = tfma<T>(-(xr * buf[w + 16 * k]), rp, a[k]);  // the product does not wait for the reciprocal
+                const T upd = tfma<T>(-(xr * buf[w + NW * k]), rp, a[k]);  // the product does not wait for the reciprocal
                 a[k] = (k > jq || w > jj) ? upd : a[k];
             }
         }
@@ -97,8 +101,8 @@ __global__ __launch_bounds__(1024) void chol_diag_kernel(T* __restrict__ A, int 
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int cc = w + 16 * k;
+    for (int k = 0; k < NC; ++k) {
+        const int cc = w + NW * k;
         T root, rinv;
         pivot_root(pivs[cc], root, rinv);
         const T l = (r == cc) ? root : (r > cc ? a[k] * rinv : T(0));
@@ -215,7 +219,7 @@ static int cholesky_impl(cglb_ctx* c, T* A, int* info_slot) {
     HIP_CHECK(c, hipMemsetAsync(info_slot, 0, sizeof(int), c->stream));
     for (int k0 = 0; k0 < n; k0 += CHOL_NB) {
         const int nb = n - k0 < CHOL_NB ? n - k0 : CHOL_NB;
-        hipLaunchKernelGGL((chol_diag_kernel<T>), dim3(1), dim3(1024), 0, c->stream, A, n, k0, nb, info_slot, Dblk);
+        hipLaunchKernelGGL((chol_diag_kernel<T>), dim3(1), dim3(64 * CHOL_DIAG_WAVES), 0, c->stream, A, n, k0, nb, info_slot, Dblk);
         CGLB_LAUNCH_CHECK(c);
         const int rest = n - k0 - nb;
         if (rest > 0) {  // nb == CHOL_NB here: a short block is the last one (rest == 0)
