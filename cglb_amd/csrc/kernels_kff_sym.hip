@@ -191,45 +191,46 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
             for (int d = 0; d < DP; ++d) xj[d] = xn[d];
         }
         if (jb >= sym_from) {  // wave-uniform
-            // R == 1 (D > 16): the in-register transpose-reduce of round 1 - those instances run 4 waves per SIMD, which the LDS
-            // scratch of the other form would cut to 3 (D = 24: 2.57 -> 2.91 ms).  Also for A/B builds (EXTRA_DEFS=-DCGLB_SYM_TR_REG=1).
+            // Column sums of the batch = sums ACROSS the 64 lanes of t[0..15].
             if constexpr (R == 1 || CGLB_SYM_TR_REG) {
+                // R == 1 (D > 16): the in-register transpose-reduce of round 1 (4 select/shuffle/add stages that halve the number of live
+                // vectors, then two butterfly adds) - those instances run 4 waves per SIMD, which the LDS scratch of the other form would
+                // cut to 3 (D = 24: 2.57 -> 2.91 ms).  Also for A/B builds (EXTRA_DEFS=-DCGLB_SYM_TR_REG=1).
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bool hi = (lane >> s) & 1;
+                for (int s = 0; s < 4; ++s) {
+                    const bool hi = (lane >> s) & 1;
 #pragma unroll
-                for (int q = 0; q < (SYM_BATCH >> (s + 1)); ++q) {
-                    const T a = t[2 * q], b = t[2 * q + 1];
-                    const T keep = hi ? b : a;
-                    const T send = hi ? a : b;
-                    t[q] = keep + __shfl_xor(send, 1 << s, 64);
+                    for (int q = 0; q < (SYM_BATCH >> (s + 1)); ++q) {
+                        const T a = t[2 * q], b = t[2 * q + 1];
+                        const T keep = hi ? b : a;
+                        const T send = hi ? a : b;
+                        t[q] = keep + __shfl_xor(send, 1 << s, 64);
+                    }
                 }
-            }
-            T v = t[0];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (lane < SYM_BATCH) cs[jb - k * chunk + lane] = v;
-            } else {
-            // Column sums of the batch = sums ACROSS the 64 lanes of t[0..15].  Transposed through LDS, 8 columns at a time: every lane
-            // writes its 8 partials (row jj of `tr`, stride SYM_TR_LD: conflict-free), then lane (c = lane & 7, g = lane >> 3) adds
-            // the 8 lanes 8g..8g+7 of column c in fixed order and three xor-shuffles add the 8 groups: 7 + 3 adds and no selects per
-            // 32 pairs, against 83 VALU instructions per 64 pairs for the in-register transpose-reduce (4 select/shuffle/add
-            // stages) this replaces.  One wave, in-order LDS: no barrier; the wave_barrier calls only pin the compiler's order.
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) tr[jj * SYM_TR_LD + lane] = t[8 * half + jj];
-                __builtin_amdgcn_wave_barrier();
-                const T* __restrict__ src = tr + (lane & 7) * SYM_TR_LD + (lane & ~7);
-                T v = src[0];
-#pragma unroll
-                for (int i = 1; i < 8; ++i) v += src[i];
-                __builtin_amdgcn_wave_barrier();
-                v += __shfl_xor(v, 8, 64);
+                T v = t[0];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
-                if (lane < 8) cs[jb - k * chunk + 8 * half + lane] = v;
-            }
+                if (lane < SYM_BATCH) cs[jb - k * chunk + lane] = v;
+            } else {
+                // Transposed through LDS, 8 columns at a time: every lane writes its 8 partials (row jj of `tr`, stride SYM_TR_LD:
+                // conflict-free), then lane (c = lane & 7, g = lane >> 3) adds the 8 lanes 8g..8g+7 of column c in fixed order and three
+                // xor-shuffles add the 8 groups: 7 + 3 adds and no selects per 32 pairs, against 83 VALU instructions per 64 pairs for the
+                // in-register form.  One wave, in-order LDS: no barrier; the wave_barrier calls only pin the compiler's order.
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) tr[jj * SYM_TR_LD + lane] = t[8 * half + jj];
+                    __builtin_amdgcn_wave_barrier();
+                    const T* __restrict__ src = tr + (lane & 7) * SYM_TR_LD + (lane & ~7);
+                    T v = src[0];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) v += src[i];
+                    __builtin_amdgcn_wave_barrier();
+                    v += __shfl_xor(v, 8, 64);
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (lane < 8) cs[jb - k * chunk + 8 * half + lane] = v;
+                }
             }
         }
     }
