@@ -244,3 +244,19 @@ def test_optimize_schedule_four_rounds_without_inducing_points_in_the_last_two(m
     FakeScipy.nits = iter([20])
     rounds.clear()
     assert [r.nit for r in interface._optimize_cglb(Model(), None, 20, logger, "scipy")] == [20] and len(rounds) == 1
+
+
+def test_optimize_narrows_and_restores_the_host_thread_pools(monkeypatch):
+    """`optimize` runs with narrow OpenMP/BLAS pools (idle workers of wide pools starve the HIP runtime's threads) and restores the
+    previous width afterwards; CGLB_HOST_THREADS=0 leaves the pools alone."""
+    import torch
+    from cglb_amd.backend.interface import _narrow_host_pools
+    before = torch.get_num_threads()
+    monkeypatch.setenv("CGLB_HOST_THREADS", "2")
+    with _narrow_host_pools():
+        assert torch.get_num_threads() == min(before, 2)
+    assert torch.get_num_threads() == before
+    monkeypatch.setenv("CGLB_HOST_THREADS", "0")
+    with _narrow_host_pools():
+        assert torch.get_num_threads() == before
+    assert torch.get_num_threads() == before
