@@ -89,9 +89,12 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
 // D + 2 accumulate instructions per pair and ~1 for the transposition (D = 8: ~31 in all, against 46 for direct differences).
 // The expansion cancels when |x_d| >> |x_id - x_jd| for the pairs that carry weight (lengthscale far below the data range): the
 // operands are centred, so the loss is ~log10((range / l)^2) of 16 digits - irrelevant against the 1e-8 the optimiser needs.
+#ifndef CGLB_GRAM_W3_DP
+#define CGLB_GRAM_W3_DP 28  // padded width whose instance is pinned to 3 waves per SIMD (175 VGPRs unpinned: 2 waves; pinned 28 B of scratch: 7.26 -> 5.62 ms at N = 60k; the same at width 32 costs 130 B of scratch: 7.4 -> 8.5 ms)
+#endif
 #define GRAD_TR_LD 65  // leading dimension of a wave's 8 x 64 transposition scratch (odd: the column reads spread over the banks)
-template <typename T, int KIND, int DP, int R, int PREC>
-__global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict__ Xh, const T* __restrict__ Xhsq, const T* __restrict__ ah,
+template <typename T, int KIND, int DP, int R, int PREC, bool CLAMP>
+__global__ __launch_bounds__(256, (DP == CGLB_GRAM_W3_DP ? 3 : 1)) void grad_kff_gram_kernel(const T* __restrict__ Xh, const T* __restrict__ Xhsq, const T* __restrict__ ah,
                                                             const T* __restrict__ u, const T* __restrict__ v, int64_t row0, int64_t n,
                                                             int64_t jchunk, int64_t blk0, int rb_stride, int rb_offset,
                                                             double* __restrict__ part, const double* __restrict__ exp_tab) {
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void grad_kff_gram_kernel(const T* __restrict_
                     for (int d = 0; d < DP; ++d) g = tfma<T>(xi[k][d], xj[d], g);
                     earg[k] = (KIND == CGLB_RBF) ? g + aj : sqrt_hot<PREC>(tfma<T>(T(-2), g, aj));  // RBF: exponent; Matern: r (exponent -r)
                 }
-                exp2_tab_batch<false, KIND != CGLB_RBF, PREC, R>(earg, tab, h);
+                exp2_tab_batch<CLAMP, KIND != CGLB_RBF, PREC, R>(earg, tab, h);  // CLAMP: exponents beyond the table's range (set_hypers decides)
                 T cj = 0;
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -271,7 +274,9 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
         HIP_CHECK(c, hipMemsetAsync(out_dl, 0, sizeof(double) * c->D, c->stream));
         return CGLB_OK;
     }
-    const bool use_gram = c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64;  // fp32 keeps direct differences: no digits to spare
+    // fp32 keeps direct differences (no digits to spare); the clamped exponent range (large scaled coordinates: wide D at short
+    // lengthscales, e.g. the reference's initial l = 1 at D >= 17) runs the same Gram form with the range clamp of the 2^x
+    const bool use_gram = c->grad_gram && c->dtype == CGLB_F64;
     const int R = c->Dp <= 8 ? 2 : 1;
     const int Rg = c->Dp <= CGLB_GRAM_R2_MAX_DP ? CGLB_GRAM_ROWS : 1;  // the Gram-form kernel (square range only)
     // three column ranges: the square block (symmetric form) and the shard's off-diagonal ranges [0,r0), [r1,N)
@@ -302,16 +307,18 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
     hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, SYMV, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh + c->r0 * DP,        \
                        (const T*)u_local, (const T*)v_full + c->r0, c->nloc, (const T*)c->Xh + r.col0 * DP, (const T*)v_full + r.col0, \
                        (const T*)u_local, r.ncols, r.jchunk, blk0, 1, 0, c->gpart, (const double*)c->exp_tab)
-#define GG_LAUNCH(RR)                                                                                                                 \
-    hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,     \
+#define GG_LAUNCH1(RR, CL)                                                                                                            \
+    hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR, PREC, CL>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq, \
                        (const T*)c->xah, (const T*)u_local - c->r0, (const T*)v_full, c->r0, c->nloc, r.jchunk, blk0, 1, 0, c->gpart,     \
                        (const double*)c->exp_tab)
+#define GG_LAUNCH(RR) do { if (c->exp_clamp) { GG_LAUNCH1(RR, true); } else { GG_LAUNCH1(RR, false); } } while (0)
         if (r.sym && use_gram) {
             // u_local is indexed by global row inside the kernel (row0 + local), hence the shifted base pointer
             CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= CGLB_GRAM_R2_MAX_DP) { GG_LAUNCH(CGLB_GRAM_ROWS); } else { GG_LAUNCH(1); }));
         } else if (r.sym) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); })); }
         else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); })); }
 #undef GG_LAUNCH
+#undef GG_LAUNCH1
 #undef GK_LAUNCH
         CGLB_LAUNCH_CHECK(c);
         blk0 += bx * r.jsplit;
@@ -331,7 +338,7 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
         sp.center[d] = 0;
         sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
     }
-    const bool use_gram = c->grad_gram && !c->exp_clamp && c->dtype == CGLB_F64;
+    const bool use_gram = c->grad_gram && c->dtype == CGLB_F64;
     const int R = use_gram ? (c->Dp <= CGLB_GRAM_R2_MAX_DP ? CGLB_GRAM_ROWS : 1) : (c->Dp <= 8 ? 2 : 1);
     const int64_t nb = (c->N + 256 * R - 1) / (256 * R);
     const int64_t bx = c->par_rank < nb ? (nb - c->par_rank + c->par_world - 1) / c->par_world : 0;
@@ -352,13 +359,15 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
     hipLaunchKernelGGL((grad_kff_kernel<T, KIND, DP, RR, true, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)u_full,  \
                        (const T*)v_full, c->N, (const T*)c->Xh, (const T*)v_full, (const T*)u_full, c->N, jchunk, (int64_t)0,       \
                        c->par_world, c->par_rank, c->gpart, (const double*)c->exp_tab)
-#define GGC_LAUNCH(RR)                                                                                                               \
-    hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR, PREC>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq,    \
+#define GGC_LAUNCH1(RR, CL)                                                                                                          \
+    hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR, PREC, CL>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq, \
                        (const T*)c->xah, (const T*)u_full, (const T*)v_full, (int64_t)0, c->N, jchunk, (int64_t)0, c->par_world, c->par_rank, \
                        c->gpart, (const double*)c->exp_tab)
+#define GGC_LAUNCH(RR) do { if (c->exp_clamp) { GGC_LAUNCH1(RR, true); } else { GGC_LAUNCH1(RR, false); } } while (0)
     if (use_gram) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= CGLB_GRAM_R2_MAX_DP) { GGC_LAUNCH(CGLB_GRAM_ROWS); } else { GGC_LAUNCH(1); })); }
     else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); })); }
 #undef GGC_LAUNCH
+#undef GGC_LAUNCH1
 #undef GKC_LAUNCH
     CGLB_LAUNCH_CHECK(c);
     hipLaunchKernelGGL(grad_dl_finalize_kernel, dim3(c->D), dim3(256), 0, c->stream, (const double*)c->gpart, nblk, c->Dp, c->D, sp,

@@ -35,6 +35,8 @@ typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane
 #ifndef CGLB_SYM_TR_REG
 #define CGLB_SYM_TR_REG 0
 #endif
+// minimum waves per SIMD asked of the compiler for the fp64 instances (padded width DP, R rows per lane); 1 = no constraint
+#define CGLB_SYM_WAVES(DP, R) (((DP) <= 8 && (R) <= 4) ? 3 : ((DP) == 32 ? 4 : 1))
 #ifndef CGLB_SYM_R4_MAX_DP
 #define CGLB_SYM_R4_MAX_DP 12  // widest padded row that still gets 4 rows per lane in fp64 (DP = 12: 3.67 -> 3.40 ms at N = 100k against 2 rows)
 #endif
@@ -277,8 +279,9 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
 // elements, writes and combine-kernel reads of one vector per (row block, chunk).
 template <typename T, int KIND, int DP, int R, bool CLAMP, int PREC>
 // waves per SIMD: fp32 4 (at D = 16 that costs a 184-byte spill and is still faster than 3 waves without: 203 vs 235 ms per mat-vec at
-// N = 1M); fp64 3 for the 4-rows-per-lane instances (D = 5..8: 160-167 VGPRs), unconstrained for 8 rows per lane (D <= 4) and D > 8
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : ((DP <= 8 && R <= 4) ? 3 : 1))) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
+// N = 1M); fp64 (CGLB_SYM_WAVES): 3 for the 4-rows-per-lane instances of D = 5..8 (160-167 VGPRs), 4 at padded width 32 (130 -> 116 VGPRs:
+// 3.43 -> 3.13 ms at N = 60k), unconstrained elsewhere (pins at widths 2, 10 and 16 measured -2 % for RBF and up to +13 % for Matern-3/2)
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : CGLB_SYM_WAVES(DP, R))) void kff_sym_kernel(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p,
                                                       const T* __restrict__ pw, const T* __restrict__ wcol,
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items,
                                                       const int2* __restrict__ groups, int rb_stride, int64_t prow_ld, T* __restrict__ Prow,

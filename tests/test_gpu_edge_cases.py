@@ -200,3 +200,27 @@ def test_ragged_inducing_counts_factorise_like_the_oracle(M, dtype):
     else:
         assert abs(res.steps - ref.steps) <= 1 and res.bound == pytest.approx(ref.bound, rel=2e-3)
 
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+@pytest.mark.parametrize("D,ls", [(20, 0.6), (8, 0.25), (27, 1.0)])
+def test_clamped_exponent_range_bound_and_gradient(kind, D, ls):
+    """Large scaled coordinates (wide D at short lengthscales - the reference's initial l = 1 at D >= 17 is such a case): the pair kernels
+    switch to their range-clamped 2^x, kernel values underflow to exact zeros far from the diagonal; bound and gradient still follow the oracle."""
+    from cglb_amd.hip_context import HipContext
+    N, M = 900, 40
+    X, y, Z = orc.synthetic_problem(N, D, M, seed=D)
+    hyp = orc.Hypers(np.full(D, ls), 1.1, 0.3, 0.05, Z, 1e-6)
+    ctx = HipContext(X, y, M, kind)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+    v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
+    res = ctx.objective_and_grad(v, True, 1e-2, 100, 40, with_grad=True)
+    ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, 1e-2, 100, 40)
+    refg = orc.objective(kind, X, y, hyp, v.cpu().numpy(), run_cg=False, with_grad=True)
+    assert abs(res.steps - ref.steps) <= 1
+    assert res.bound == pytest.approx(refg.bound, rel=1e-10)
+    for key in ("lengthscales", "Z"):
+        scale = np.abs(refg.grad[key]).max() + 1e-300
+        np.testing.assert_allclose(res.grad[key], refg.grad[key], rtol=0, atol=1e-8 * scale + 1e-12 * abs(refg.bound))
+    assert res.grad["noise"] == pytest.approx(refg.grad["noise"], rel=1e-8)
+    assert res.grad["variance"] == pytest.approx(refg.grad["variance"], rel=1e-8, abs=1e-10 * abs(refg.bound))
