@@ -256,6 +256,10 @@ static int ensure_gpart(cglb_ctx* c, size_t need) {
 #ifndef CGLB_GRAM_R2_MAX_DP
 #define CGLB_GRAM_R2_MAX_DP 12  // widest padded row with CGLB_GRAM_ROWS rows per lane in the Gram-form kernel (DP = 12: 8.4 -> 7.2 ms at N = 100k against 1 row)
 #endif
+#ifndef CGLB_GRAM_R4_MAX_DP
+#define CGLB_GRAM_R4_MAX_DP 4  // widest padded row with FOUR rows per lane (D <= 4: -6..-8 % against two)
+#endif
+#define CGLB_GRAM_ROWS_OF(dp) ((dp) <= CGLB_GRAM_R4_MAX_DP ? 4 : ((dp) <= CGLB_GRAM_R2_MAX_DP ? CGLB_GRAM_ROWS : 1))
 #ifndef CGLB_GRAM_ROWS
 #define CGLB_GRAM_ROWS 2
 #endif
@@ -278,7 +282,7 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
     // lengthscales, e.g. the reference's initial l = 1 at D >= 17) runs the same Gram form with the range clamp of the 2^x
     const bool use_gram = c->grad_gram && c->dtype == CGLB_F64;
     const int R = c->Dp <= 8 ? 2 : 1;
-    const int Rg = c->Dp <= CGLB_GRAM_R2_MAX_DP ? CGLB_GRAM_ROWS : 1;  // the Gram-form kernel (square range only)
+    const int Rg = CGLB_GRAM_ROWS_OF(c->Dp);  // the Gram-form kernel (square range only)
     // three column ranges: the square block (symmetric form) and the shard's off-diagonal ranges [0,r0), [r1,N)
     struct Range { int64_t col0, ncols; bool sym; int64_t jsplit, jchunk; } rg[3] = {
         {c->r0, c->nloc, true, 0, 0}, {0, c->r0, false, 0, 0}, {c->r1, c->N - c->r1, false, 0, 0}};
@@ -314,7 +318,7 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
 #define GG_LAUNCH(RR) do { if (c->exp_clamp) { GG_LAUNCH1(RR, true); } else { GG_LAUNCH1(RR, false); } } while (0)
         if (r.sym && use_gram) {
             // u_local is indexed by global row inside the kernel (row0 + local), hence the shifted base pointer
-            CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= CGLB_GRAM_R2_MAX_DP) { GG_LAUNCH(CGLB_GRAM_ROWS); } else { GG_LAUNCH(1); }));
+            CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, GG_LAUNCH(CGLB_GRAM_ROWS_OF(DP))));
         } else if (r.sym) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); })); }
         else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); })); }
 #undef GG_LAUNCH
@@ -339,7 +343,7 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
         sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
     }
     const bool use_gram = c->grad_gram && c->dtype == CGLB_F64;
-    const int R = use_gram ? (c->Dp <= CGLB_GRAM_R2_MAX_DP ? CGLB_GRAM_ROWS : 1) : (c->Dp <= 8 ? 2 : 1);
+    const int R = use_gram ? CGLB_GRAM_ROWS_OF(c->Dp) : (c->Dp <= 8 ? 2 : 1);
     const int64_t nb = (c->N + 256 * R - 1) / (256 * R);
     const int64_t bx = c->par_rank < nb ? (nb - c->par_rank + c->par_world - 1) / c->par_world : 0;
     if (bx == 0) {
@@ -364,7 +368,7 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
                        (const T*)c->xah, (const T*)u_full, (const T*)v_full, (int64_t)0, c->N, jchunk, (int64_t)0, c->par_world, c->par_rank, \
                        c->gpart, (const double*)c->exp_tab)
 #define GGC_LAUNCH(RR) do { if (c->exp_clamp) { GGC_LAUNCH1(RR, true); } else { GGC_LAUNCH1(RR, false); } } while (0)
-    if (use_gram) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= CGLB_GRAM_R2_MAX_DP) { GGC_LAUNCH(CGLB_GRAM_ROWS); } else { GGC_LAUNCH(1); })); }
+    if (use_gram) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, GGC_LAUNCH(CGLB_GRAM_ROWS_OF(DP)))); }
     else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); })); }
 #undef GGC_LAUNCH
 #undef GGC_LAUNCH1
