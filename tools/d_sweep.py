@@ -10,7 +10,7 @@ from cglb_amd.data import synthetic_problem, trained_like_hypers
 from cglb_amd.hip_context import HipContext
 N, M = 60000, 64
 out = []
-for D in (1, 2, 3, 4, 6, 8, 12, 16, 18, 20, 24, 27, 28, 32):
+for D in (1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 20, 24, 27, 28, 32):
     X, y, Z = synthetic_problem(N, D, M, 0)
     h = trained_like_hypers(D)
     for kind in ("rbf", "matern32"):
