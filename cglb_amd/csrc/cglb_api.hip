@@ -675,7 +675,7 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
     CGLB_TRY(launch_hot_squares(c));
     CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zs, c->za));
     CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zh, c->zah, true));
-    CGLB_TRY(launch_frag_prep(c));
+    c->frag_valid = false;  // the pre-permuted operands of the experimental matrix-pipe variant are rebuilt on its first use
     c->have_local = c->have_terms = false;
     return CGLB_OK;
 }

@@ -61,6 +61,7 @@ struct cglb_ctx {
     void* Guf = nullptr;     // adjoint of Kuf, same layout as At (allocated on first gradient)
     void *fragA = nullptr, *fragB = nullptr;  // MFMA-ordered augmented operands (kernels_kff_mfma.hip)
     size_t frag_cap = 0;
+    bool frag_valid = false;  // fragA / fragB (operands of the experimental matrix-pipe variant) match the current hypers
     void* sym_items = nullptr;       // work list (row block, column chunk) of the symmetric mat-vec
     int64_t sym_n = -1, sym_chunk = 0, sym_chunk_opt = 0;
     double sym_pairs = 0.0;          // kernel pairs one launch of the symmetric pair kernel evaluates (current item list)

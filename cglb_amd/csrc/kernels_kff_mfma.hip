@@ -200,6 +200,10 @@ int launch_kff_mfma_pairs(cglb_ctx* c, const double* p_full, int64_t* jsplit_out
         HIP_CHECK(c, hipMalloc(&c->kpart, need));
         c->kpart_cap = need;
     }
+    if (!c->frag_valid) {
+        CGLB_TRY(launch_frag_prep(c));
+        c->frag_valid = true;
+    }
     const double* FA = (const double*)c->fragA + (c->r0 / 16) * KA * 64;
     double* part = (double*)c->kpart;
 #define MF(KAV)                                                                                      \
