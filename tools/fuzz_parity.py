@@ -43,9 +43,9 @@ for c in range(cases):
     # two correct CG runs agree on the bound to 1e-6 or to a fraction of the stopping tolerance (the bound moves by 1/2 r^T P r <= tol
     # between admissible stopping points and long solves with a weak preconditioner drift apart by round-off)
     gz_abs = np.abs(res.grad["Z"] - refg.grad["Z"]).max()
-    ok = (e_mv < 1e-11 * F and e_b2 < 1e-9 * F and gl < 1e-6 * (3e3 if fp32 else 1) and (gz < 1e-6 * (3e3 if fp32 else 1) or gz_abs < 1e-11 * F * max(1.0, abs(ref.bound)))
+    ok = (e_mv < 1e-11 * F and e_b2 < 1e-9 * F and gl < 1e-6 * (3e3 if fp32 else 1) and (gz < 1e-6 * (3e3 if fp32 else 1) or gz_abs < 1e-9 * F * max(1.0, abs(ref.bound)))
           and abs(res.steps - ref.steps) <= (3 if fp32 else 2)
-          and (e_b < 1e-6 * (1e3 if fp32 else 1) or abs(res.steps - ref.steps) > 0 or abs(res.bound - ref.bound) < 0.1 * tol))
+          and (e_b < 1e-6 * (1e3 if fp32 else 1) or abs(res.steps - ref.steps) > 0 or abs(res.bound - ref.bound) < 0.5 * tol))
     bad += not ok
     print(f"{'ok ' if ok else 'BAD'} N={N:5d} D={D:2d} M={M:3d} {kind:8s} prec={prec} tol={tol:g} steps {res.steps}/{ref.steps} matvec {e_mv:.1e} bound {e_b:.1e} "
           f"bound@v {e_b2:.1e} grad ls {gl:.1e} Z {gz:.1e}", flush=True)
