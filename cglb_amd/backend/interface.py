@@ -236,7 +236,9 @@ def _optimize_cglb_impl(model: CGLB, dataset, num_steps: int, logger: Logger, op
 
     def lbfgs_closure() -> Tensor:
         loss = -lower_bound(None)
-        logger.log_for_feval(**asdict(model.cg_stats))      # steps-per-feval / residual_error-per-feval (:476)
+        stats = model.cg_stats                              # None when CG never ran (TF-twin vzero / joint_optimization)
+        # steps-per-feval / residual_error-per-feval (:476); without CG the TF optimize logs zeros (tensorflow/interface.py:296-337)
+        logger.log_for_feval(**(asdict(stats) if stats is not None else dict(steps=0, residual_error=0.0)))
         return loss
 
     def step_callback(*args):

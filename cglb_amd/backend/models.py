@@ -11,6 +11,7 @@ models.py:257-274).
 from __future__ import annotations
 
 import math
+import weakref
 from dataclasses import dataclass
 from typing import Optional, Tuple, Union
 
@@ -162,19 +163,31 @@ class CGLB(SGPR):
         self._hyper_token = None
 
     def check_same_data(self, data: Data) -> None:
-        """ValueError unless (x, y) is the training set the HIP context was built on (same shapes and content)."""
+        """ValueError unless (x, y) is the training set the HIP context was built on (same shapes and content).  The full comparison
+        runs once per data object: the last accepted pair is remembered (weakly), so an
+        optimiser that hands over the same arrays at every evaluation does not pay N*D comparisons inside its loop."""
         x, y = data
         if x is self.train_inputs[0] and y is self.train_targets:
             return
+        accepted = getattr(self, "_accepted_data", None)   # weak references to the last pair that passed the full comparison
+        if accepted is not None and accepted[0]() is x and accepted[1]() is y:
+            return
+        x_in, y_in = x, y
+        # everything on the host in fp64, whatever device the model or the caller keep their tensors on
         x = torch.as_tensor(x).detach().cpu().to(torch.float64)
         y = torch.as_tensor(y).detach().cpu().to(torch.float64).reshape(-1)
         x = x.reshape(x.shape[0], -1) if x.ndim else x.reshape(1, 1)
-        tx, ty = self.train_inputs[0].to(torch.float64), self.train_targets.to(torch.float64).reshape(-1)
+        tx = self.train_inputs[0].detach().cpu().to(torch.float64)
+        ty = self.train_targets.detach().cpu().to(torch.float64).reshape(-1)
         if x.shape != tx.shape or y.shape != ty.shape:
             raise ValueError(f"LowerBoundCG was given data of shape {tuple(x.shape)}/{tuple(y.shape)} but the model holds the training set "
                              f"{tuple(tx.shape)}/{tuple(ty.shape)}: the bound is only defined on the model's own training data")
         if not (torch.equal(y, ty) and torch.equal(x, tx)):
             raise ValueError("LowerBoundCG was given data that differs from the model's training set")
+        try:
+            self._accepted_data = (weakref.ref(x_in), weakref.ref(y_in))
+        except TypeError:  # lists / scalars cannot be weakly referenced: compared in full every time
+            self._accepted_data = None
 
     def _build_v_vec(self) -> Tensor:  # models.py:59-68
         return torch.zeros((self.hip.N, 1), dtype=self.dtype, device=self.hip.device, requires_grad=False)

@@ -322,6 +322,9 @@ int require_single(cglb_ctx* c) {
 // ---- PCG (conjugate_gradient.py:41-86) ----------------------------------------------------------------------
 int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter, int restart_iter, int* steps, double* half_rz) {
     double* S = c->scal;
+    // A weighted copy p o w left behind by the LAST update of an earlier solve (loop left without a look-ahead mat-vec) must not be
+    // taken for the operand of this solve's first mat-vec: the direction vector is rewritten below.
+    c->pwh_src = nullptr;
     // :57-61  Av = A v ; r = b - Av ; z, rz = P(r) ; p = z
     // A cold start (v == 0, models.py:59-68) gives Av == 0 and r == b exactly, so the mat-vec is skipped in that case;
     // the result is bit-identical to computing it.
@@ -336,7 +339,7 @@ int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter
     }
     double *s_rz = S + S_RZ, *s_nrz = S + S_NRZ;  // the two slots swap roles every iteration (:76) instead of being copied
     CGLB_TRY(precond_single(c, c->w_r, c->w_z, s_rz));
-    HIP_CHECK(c, hipMemcpyAsync(c->w_p, c->w_z, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
+    CGLB_TRY(launch_update_p(c, c->w_p, c->w_z, s_rz, s_rz, 1, -1, true));  // :61 p = z (+ the weighted copy for the first mat-vec)
     double rz = 0;
     CGLB_TRY(read_scalars(c, s_rz, &rz, 1));
     // The stop predicate (:65) is evaluated on the host, like the reference's (:80-81).  Look-ahead: while the residual is
@@ -399,6 +402,7 @@ int ensure_Linv(cglb_ctx* c) {
     HIP_CHECK(c, hipMemcpyAsync(c->Linv, c->Lc, (size_t)M * M * c->esz, hipMemcpyDeviceToDevice, c->stream));
     BLAS_CHECK(c, xtrtri(c->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, M, (T*)c->Linv, M, c->info_dev + 2));
     c->have_Linv = true;
+    c->Linv_unchecked = true;  // info_dev[2] is read with the next host read-back of the evaluation (obj_finish)
     return CGLB_OK;
 }
 
@@ -488,7 +492,13 @@ double logdet_value(const cglb_ctx* c) {
 
 int obj_finish(cglb_ctx* c, const double* sc_dev, double* out4) {
     double sc[8];
+    rocblas_int info_inv = 0;
+    if (c->Linv_unchecked) HIP_CHECK(c, hipMemcpyAsync(&info_inv, c->info_dev + 2, sizeof(info_inv), hipMemcpyDeviceToHost, c->stream));
     CGLB_TRY(read_scalars(c, sc_dev, sc, 8));
+    if (c->Linv_unchecked) {
+        c->Linv_unchecked = false;
+        if (info_inv != 0) { c->have_Linv = false; return cglb_fail(c, CGLB_ERR_NOT_PD, "inverse of L (gradient algebra) failed: zero pivot " + std::to_string(info_inv)); }
+    }
     const double N = (double)c->N;
     const double lower = sc[0], upper = sc[0] + 0.5 * sc[1];           // models.py:283-284
     const double logdet = logdet_value(c);
@@ -764,9 +774,12 @@ int cglb_precond_apply(cglb_ctx* c, const void* r, void* z, double* rz) {
 }
 
 int cglb_shard_precond_u(cglb_ctx* c, const void* r_local, void* u_partial) {
-    if (!c || !r_local || !u_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    // a rank whose row shard is empty (nloc == 0: more ranks than row blocks) passes an empty vector, whose pointer may be NULL:
+    // its partial u is zero
+    if (!c || (!r_local && c->nloc > 0) || !u_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     CGLB_TRY(require_terms(c));
     HIP_CHECK(c, hipSetDevice(c->device));
+    if (c->nloc == 0) { HIP_CHECK(c, hipMemsetAsync(u_partial, 0, (size_t)c->M * c->esz, c->stream)); return CGLB_OK; }
     return precond_u_any(c, r_local, u_partial);
 }
 int cglb_shard_precond_z(cglb_ctx* c, const void* r_local, const void* u, void* z_local, void* rz_partial) {
@@ -780,11 +793,15 @@ int cglb_shard_precond_z(cglb_ctx* c, const void* r_local, const void* u, void* 
 
 int cglb_shard_precond_z_seg(cglb_ctx* c, const void* r_local, const void* u, void* z_slot, int64_t per) {
     if (c) c->obj_valid = false;
-    if (!c || !r_local || !u || !z_slot || per < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    if (!c || (!r_local && c->nloc > 0) || !u || !z_slot || per < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
     if (per < c->nloc) return cglb_fail(c, CGLB_ERR_BAD_ARG, "precond_z_seg: slice shorter than the local rows");
     if (c->precond_mode != 0) return cglb_fail(c, CGLB_ERR_STATE, "precond_z_seg needs the stored-panel preconditioner (precond_mode 0)");
     CGLB_TRY(require_terms(c));
     HIP_CHECK(c, hipSetDevice(c->device));
+    if (c->nloc == 0) {  // empty shard: nothing to precondition, the partial of r^T z is zero
+        HIP_CHECK(c, hipMemsetAsync((char*)z_slot + (size_t)per * c->esz, 0, c->esz, c->stream));
+        return CGLB_OK;
+    }
     CGLB_TRY(launch_tri_apply(c, u, c->w_t));
     return launch_precond_z(c, r_local, c->w_t, z_slot, nullptr, (char*)z_slot + (size_t)per * c->esz);
 }

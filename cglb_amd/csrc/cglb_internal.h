@@ -57,6 +57,7 @@ struct cglb_ctx {
     void* Mtmp2 = nullptr;   // M x M scratch
     void* Mtmp3 = nullptr;   // M x M scratch of the gradient algebra (allocated on first use)
     bool have_Linv = false;  // Linv holds L^-1 of the current K_uu factor
+    bool Linv_unchecked = false;  // the trtri status of Linv (info_dev[2]) has not been read back yet
     int grad_trsm = 0;       // 1: rocBLAS trsm / trsv against L in the gradient algebra instead of products with the explicit L^-1
     void* Guf = nullptr;     // adjoint of Kuf, same layout as At (allocated on first gradient)
     void *fragA = nullptr, *fragB = nullptr;  // MFMA-ordered augmented operands (kernels_kff_mfma.hip)

@@ -153,14 +153,17 @@ class PCGStats:
 def pcg(matvec: Callable[[np.ndarray], np.ndarray], b: np.ndarray, v0: np.ndarray,
         precond: Callable[[np.ndarray], Tuple[np.ndarray, float]],
         max_error: float = 1.0, max_cg_iter: int = 100, restart_cg_iter: int = 40,
-        ) -> Tuple[np.ndarray, PCGStats]:
-    """conjugate_gradient.py:41-86, operation for operation (vectors are [N])."""
+        history: Optional[list] = None) -> Tuple[np.ndarray, PCGStats]:
+    """conjugate_gradient.py:41-86, operation for operation (vectors are [N]).  `history` (test aid, not in the reference): receives
+    the stop statistic 1/2 r^T P r every time the predicate of :65 reads it, so history[k] is the value tested before iteration k."""
     v = v0.copy()  # :55
     Av = matvec(v)  # :57
     r = b - Av  # :58
     z, rz = precond(r)  # :59
     p = z  # :61
     i = 0
+    if history is not None:
+        history.append(0.5 * rz)
     while (0.5 * rz > max_error) and (i < max_cg_iter):  # :65
         Ap = matvec(p)  # :66
         gamma = rz / float((p * Ap).sum())  # :67
@@ -171,6 +174,8 @@ def pcg(matvec: Callable[[np.ndarray], np.ndarray], b: np.ndarray, v0: np.ndarra
         p = z if restart else (z + p * new_rz / rz)  # :75
         rz = new_rz  # :76
         i += 1  # :77
+        if history is not None:
+            history.append(0.5 * rz)
     return v, PCGStats(steps=i, residual_error=0.5 * rz)  # :83-86
 
 
@@ -223,6 +228,88 @@ def objective(kind, X, y, hyp: Hypers, v0: np.ndarray, run_cg: bool = True,
         out.grad = objective_grad(kind, X, hyp, terms, v, w)
         # TF twin (tensorflow/models.py:161-164, `joint_optimization`): v itself is a variable there; d bound / d v = K w - r
         out.grad["v"] = cov @ w - r
+    return out
+
+
+# --------------------------------------------------------------------------- round-off sensitivity of the oracle itself
+@dataclass
+class Sensitivity:
+    """What the oracle's OWN answers do when its inputs move at the round-off level (`roundoff_sensitivity`)."""
+
+    bound: float  # unperturbed
+    steps: int
+    history: list  # 1/2 r^T P r read by the stop test before iteration k (unperturbed run)
+    bound_spread: float  # max over probes |bound_p - bound|
+    steps_spread: int  # max over probes |steps_p - steps|
+    stat_rel_spread: np.ndarray  # per k: max over probes |h_p[k] - h[k]| / h[k] on the common prefix of the histories
+
+
+def roundoff_sensitivity(kind, X, y, hyp: Hypers, v0: np.ndarray, max_error: float = 1.0, max_cg_iter: int = 100,
+                         restart_cg_iter: int = 40, delta: float = 2.0 ** -52, probes: int = 4, seed: int = 0,
+                         cov: Optional[np.ndarray] = None) -> Sensitivity:
+    """Parity criterion for CG-path quantities, derived instead of tuned.  A PCG solve is a chaotic map once Lanczos orthogonality is
+    lost (weak preconditioner, tens of steps): two CORRECT implementations whose mat-vecs agree to `delta` relative end at bounds that
+    differ by far more than `delta`, and may stop one step apart when the stop statistic passes the tolerance within its own noise.
+    How much is measured on the oracle itself: the solve of conjugate_gradient.py:41-86 is repeated `probes` times with the dense
+    operator multiplied entry-wise by (1 + delta E), E symmetric with entries uniform in [-1, 1], and the bound (models.py:280-286,
+    assembled with the unperturbed operator at each probe's v) and step count are compared with the unperturbed run.
+    A test may then accept |bound_hip - bound| <= k * bound_spread and a step difference that a probe shows as well - and otherwise
+    holds the HIP path to north_star's 1e-6 and to the exact step count.  `delta`: the relative accuracy of the kernel values the
+    implementation under test documents (2^-52 for exactly rounded values)."""
+    N = X.shape[0]
+    if cov is None:
+        cov = dense_cov(kind, X, hyp)
+    terms = common_terms(kind, X, hyp)
+    err = y.reshape(-1) - hyp.mean
+    precon = lambda r: nystrom_precond(terms.A, terms.LB, hyp.noise, r)
+
+    def bound_at(v):
+        cov_v = cov @ v
+        r = err - cov_v
+        _, eb = precon(r)
+        lower = float((v * (r + 0.5 * cov_v)).sum())
+        return -(lower + 0.5 * eb)  # the v-dependent part of the bound (logdet and const do not depend on v)
+
+    h0: list = []
+    v, st = pcg(lambda x: cov @ x, err, v0.reshape(-1), precon, max_error, max_cg_iter, restart_cg_iter, history=h0)
+    b0 = bound_at(v)
+    rng = np.random.default_rng(seed)
+    b_spread, s_spread = 0.0, 0
+    rel = np.zeros(len(h0))
+    for _ in range(probes):
+        E = rng.uniform(-1.0, 1.0, size=(N, N))
+        E = np.triu(E) + np.triu(E, 1).T
+        covp = cov * (1.0 + delta * E)
+        del E
+        hp: list = []
+        vp, stp = pcg(lambda x: covp @ x, err, v0.reshape(-1), precon, max_error, max_cg_iter, restart_cg_iter, history=hp)
+        b_spread = max(b_spread, abs(bound_at(vp) - b0))
+        s_spread = max(s_spread, abs(stp.steps - st.steps))
+        n = min(len(hp), len(h0))
+        rel[:n] = np.maximum(rel[:n], np.abs(np.asarray(hp[:n]) - np.asarray(h0[:n])) / np.maximum(np.abs(h0[:n]), 1e-300))
+        del covp
+    logdet = logdet_estimator(kind, X, hyp, terms)
+    const = -0.5 * N * math.log(2.0 * math.pi)
+    return Sensitivity(bound=b0 + logdet + const, steps=st.steps, history=h0, bound_spread=b_spread, steps_spread=s_spread,
+                       stat_rel_spread=rel)
+
+
+def grad_roundoff_spread(kind, X, hyp: Hypers, v: np.ndarray, w: np.ndarray, probes: int = 3, seed: int = 0,
+                         delta: float = 2.0 ** -52) -> Dict[str, float]:
+    """Absolute noise floor of the analytic gradient at a FIXED (v, w): the largest change of each gradient block when the inducing
+    points and lengthscales move by `delta` relative (the backward error any Cholesky / triangular solve of K_uu commits).  With
+    cond(K_uu) ~ 1e8 (inducing points on nearly every datum) the Z gradient carries ~cond * eps of absolute error in ANY
+    implementation; a test accepts a deviation of k times this floor and otherwise holds the HIP gradient to 1e-6 relative."""
+    base = objective_grad(kind, X, hyp, common_terms(kind, X, hyp), v, w)
+    rng = np.random.default_rng(seed)
+    out = {k: 0.0 for k in base}
+    for _ in range(probes):
+        hp = hyp.copy()
+        hp.Z = hp.Z * (1.0 + delta * rng.uniform(-1.0, 1.0, size=hp.Z.shape))
+        hp.lengthscales = hp.lengthscales * (1.0 + delta * rng.uniform(-1.0, 1.0, size=hp.lengthscales.shape))
+        g = objective_grad(kind, X, hp, common_terms(kind, X, hp), v, w)
+        for k in base:
+            out[k] = max(out[k], float(np.max(np.abs(np.asarray(g[k]) - np.asarray(base[k])))))
     return out
 
 

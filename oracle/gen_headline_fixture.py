@@ -91,6 +91,10 @@ CASES = {
     "headline_rbf_trained": ("rbf", 100_000, 8, 1024, 0, "trained"),        # bench.py's default workload
     "headline_m32_trained": ("matern32", 100_000, 8, 1024, 0, "trained"),
     "c2_rbf_trained": ("rbf", 50_000, 8, 1024, 0, "trained"),               # BASELINE config C2
+    # BASELINE configs C3 / C4 at their sizes, solves cut short by max_cg_iter so that the CPU side stays within ~1 h on 8 cores:
+    # name: kind, N, D, M, seed, hypers, max_error, max_cg_iter
+    "c3_m32_short": ("matern32", 200_000, 8, 2048, 0, "trained", 1.0, 5),
+    "c4_rbf_short": ("rbf", 430_000, 3, 1024, 0, "trained", 1.0, 2),
 }
 
 

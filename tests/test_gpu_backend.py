@@ -300,3 +300,43 @@ def test_tf_twin_config_semantics_max_error_vzero_and_joint_optimisation():
         np.testing.assert_array_equal(m.v_vec.detach().cpu().numpy().reshape(-1), v0)      # no CG ran: v untouched
     finally:
         be.configure_backend(logdir="/tmp/cglb_amd_test", keops=False)                    # back to the default semantics
+
+
+@pytest.mark.parametrize("cfg_kw", [dict(vzero=True), dict(joint_optimization=True)])
+def test_optimize_under_tf_twin_semantics_without_cg(cfg_kw, tmp_path):
+    """`optimize` with the TF twin's vzero / joint_optimization: CG never runs, model.cg_stats stays None and the per-evaluation log
+    carries zeros (the TF optimize logs the CG statistics of a model that has none as 0, tensorflow/interface.py:296-337)."""
+    from cglb_amd.backend import BACKENDS, CGLBConfig, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS
+    from cglb_amd.backend.callbacks import Logger
+    be = BACKENDS["hip"]
+    train, test = _data()
+    try:
+        be.configure_backend(logdir="/tmp/cglb_amd_test", keops=False, config_semantics="tf")
+        be.set_default_float("fp64")
+        be.set_default_jitter("fp64")
+        model = be.create_model(CGLBConfig(KERNEL_CONFIGS["rbf"](), INDUCING_VARIABLE_CONFIGS["cv"](12), **cfg_kw), train)
+        logger = Logger(str(tmp_path), lambda: {}, lambda: be.model_parameters(model), holdout_interval=-1, include_feval_log=True, verbose=False)
+        results = be.optimize(model, train, 4, logger, "scipy")
+        assert model.cg_stats is None and sum(r.nit for r in results) >= 1
+        assert set(logger.logs["steps-per-feval"]) == {0} and set(logger.logs["residual_error-per-feval"]) == {0.0}
+        assert np.isfinite(float(model.last_bound))
+    finally:
+        be.configure_backend(logdir="/tmp/cglb_amd_test", keops=False)
+
+
+def test_lower_bound_accepts_the_training_set_from_any_device():
+    """LowerBoundCG.forward(data): the model's own training set passes whether it arrives as numpy arrays, CPU tensors or CUDA tensors
+    (no device-mismatch RuntimeError), anything else is a ValueError; the full comparison runs once per data object."""
+    from cglb_amd.backend.models import LowerBoundCG
+    be, model, (train, test) = _model("rbf")
+    lb = LowerBoundCG(model)
+    ref = float(lb(None))
+    xd, yd = torch.as_tensor(train[0]).cuda(), torch.as_tensor(train[1]).cuda()
+    assert float(lb((xd, yd))) == pytest.approx(ref, rel=1e-12)
+    assert model._accepted_data[0]() is xd
+    assert float(lb((xd, yd))) == pytest.approx(ref, rel=1e-12)            # second call: identity shortcut
+    assert float(lb((train[0], train[1]))) == pytest.approx(ref, rel=1e-12)
+    with pytest.raises(ValueError):
+        lb((xd + 1.0, yd))
+    with pytest.raises(ValueError):
+        lb((test[0], test[1]))

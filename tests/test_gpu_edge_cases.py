@@ -224,3 +224,34 @@ def test_clamped_exponent_range_bound_and_gradient(kind, D, ls):
         np.testing.assert_allclose(res.grad[key], refg.grad[key], rtol=0, atol=1e-8 * scale + 1e-12 * abs(refg.bound))
     assert res.grad["noise"] == pytest.approx(refg.grad["noise"], rel=1e-8)
     assert res.grad["variance"] == pytest.approx(refg.grad["variance"], rel=1e-8, abs=1e-10 * abs(refg.bound))
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+def test_consecutive_cold_start_solves_on_one_context(kind):
+    """Two cold-start solves with different right-hand sides on ONE context (and then a cold-start evaluation): the weighted copy
+    p o w that the last direction update of a solve leaves behind must not be taken for the operand of the next solve's first
+    mat-vec (the stop without a look-ahead mat-vec - max_iter reached, or the residual dropped by less than 4x - leaves it unconsumed)."""
+    from cglb_amd.hip_context import HipContext
+    N, D, M = 700, 8, 16
+    X, y, Z = orc.synthetic_problem(N, D, M, seed=21)
+    hyp = orc.trained_like_hypers(D, Z)
+    ctx = HipContext(X, y, M, kind)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+    ctx.setup()
+    terms = orc.common_terms(kind, X, hyp)
+    cov = orc.dense_cov(kind, X, hyp)
+    rng = np.random.default_rng(3)
+    for trial, max_iter in enumerate((7, 7, 100)):          # 7: leaves the loop at max_iter, right after a fused direction update
+        b = rng.standard_normal(N) * (1.0 + trial)
+        v, steps, half = ctx.pcg(b, np.zeros(N), 1e-8, max_iter, 40)
+        ref_v, st = orc.pcg(lambda x: cov @ x, b, np.zeros(N), lambda r: orc.nystrom_precond(terms.A, terms.LB, hyp.noise, r), 1e-8, max_iter, 40)
+        ref_steps = st.steps
+        assert abs(steps - ref_steps) <= (0 if max_iter == 7 else 1), (trial, steps, ref_steps)
+        if steps == ref_steps:
+            np.testing.assert_allclose(v.cpu().numpy(), ref_v, rtol=0, atol=1e-8 * np.abs(ref_v).max(), err_msg=f"solve {trial}")
+    # a cold-start evaluation right after a solve on the same context
+    vz = torch.zeros(N, dtype=torch.float64, device=ctx.device)
+    res = ctx.objective_and_grad(vz, True, 1.0, 100, 40, with_grad=False)
+    ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, 1.0, 100, 40)
+    assert res.steps == ref.steps and res.bound == pytest.approx(ref.bound, rel=1e-10)
+    ctx.close()

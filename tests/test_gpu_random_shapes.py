@@ -1,10 +1,13 @@
 """Randomised parity sweep: shapes off every tile grid (N, D, M drawn at random, both kernels, both precision levels) against the dense
-numpy oracle - mat-vec, bound at the oracle's own v, gradient, and the CG step count.  `tools/fuzz_parity.py` runs longer sweeps."""
+numpy oracle - mat-vec, bound at the oracle's own v, gradient, and the CG step count - plus the named draws of earlier long sweeps
+that needed an explanation.  `tools/fuzz_parity.py` runs longer sweeps with the same acceptance rules (`check_case`): fixed
+tolerances for everything that does not depend on the CG path; for the CG path exact agreement unless the oracle's OWN answer moves
+under a kernel-accuracy-sized perturbation of its operator, in which case a small multiple of that measured spread is admissible
+(oracle.roundoff_sensitivity; DESIGN.md section 2 "parity policy")."""
 import numpy as np
 import pytest
-import torch
 
-from oracle import cglb_oracle as orc
+from tools.fuzz_parity import check_case, named_case
 
 pytestmark = pytest.mark.gpu
 
@@ -13,42 +16,47 @@ def _draw(rng):
     N = int(rng.choice([rng.integers(2, 300), rng.integers(300, 3000), rng.integers(3000, 7000)]))
     D = int(rng.integers(1, 33))
     M = int(min(N, rng.choice([rng.integers(1, 70), rng.integers(60, 200), rng.integers(200, 600)])))
-    return N, D, M, str(rng.choice(["rbf", "matern32"])), int(rng.integers(0, 2)), float(rng.choice([1.0, 1e-2])), int(rng.integers(1 << 30))
+    kind, prec, tol, seed = str(rng.choice(["rbf", "matern32"])), int(rng.integers(0, 2)), float(rng.choice([1.0, 1e-2])), int(rng.integers(1 << 30))
+    ls = rng.uniform(0.7, 2.5, size=D) * np.sqrt(D / 2.0)
+    variance, noise, mean = float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.02, 0.5)), float(rng.normal() * 0.1)
+    return dict(N=N, D=D, M=M, kind=kind, prec=prec, tol=tol, data_seed=seed, ls=ls, variance=variance, noise=noise, mean=mean,
+                p=rng.standard_normal(N), jitter=1e-6)
 
 
 @pytest.mark.parametrize("case", range(14))
 def test_random_shape_matches_oracle(case):
-    from cglb_amd.hip_context import HipContext
-    rng = np.random.default_rng(1000 + case)
-    N, D, M, kind, prec, tol, seed = _draw(rng)
-    X, y, Z = orc.synthetic_problem(max(N, M, 8), D, M, seed=seed)
-    X, y = X[:N], y[:N]
-    ls = rng.uniform(0.7, 2.5, size=D) * np.sqrt(D / 2.0)
-    hyp = orc.Hypers(ls, float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.02, 0.5)), float(rng.normal() * 0.1), Z, 1e-6)
-    ctx = HipContext(X, y, M, kind)
-    ctx.set_option("precision", prec)
-    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
-    v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
-    res = ctx.objective_and_grad(v, True, tol, 100, 40, with_grad=True)
-    ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, tol, 100, 40)
-    refg = orc.objective(kind, X, y, hyp, v.cpu().numpy(), run_cg=False, with_grad=True)   # bound and gradient at the GPU's own v
-    p = rng.standard_normal(N)
-    Ap = ctx.matvec(torch.from_numpy(p)).cpu().numpy()
-    Aref = orc.dense_cov(kind, X, hyp) @ p
-    info = f"N={N} D={D} M={M} {kind} precision={prec} tol={tol}"
-    np.testing.assert_allclose(Ap, Aref, rtol=0, atol=1e-11 * np.abs(Aref).max(), err_msg=info)
-    assert abs(res.steps - ref.steps) <= 1, info
-    assert res.bound == pytest.approx(refg.bound, rel=1e-9), info
-    if res.steps == ref.steps:
-        # the north_star tolerance; beyond a restart (40 steps) two correct solves have drifted apart by round-off and agree only to a
-        # fraction of the stopping tolerance itself (the bound moves by 1/2 r^T P r <= max_error between admissible stopping points)
-        assert res.bound == pytest.approx(ref.bound, rel=1e-6, abs=(0.5 * tol if res.steps > 40 else 0.0)), info
-    for key in ("lengthscales", "Z"):
-        # relative to the largest entry, with a floor tied to the bound: with M = N (inducing points on every datum, K_uu as ill
-        # conditioned as K_ff) the whole Z gradient is ~1e-11 of the bound and carries cond(K_uu) * eps of absolute error on both sides
-        scale = np.abs(refg.grad[key]).max() + 1e-300
-        np.testing.assert_allclose(res.grad[key], refg.grad[key], rtol=0, atol=1e-6 * scale + 1e-11 * max(1.0, abs(ref.bound)),
-                                   err_msg=info + " grad " + key)
-    for key in ("variance", "noise", "mean"):
-        assert res.grad[key] == pytest.approx(refg.grad[key], rel=1e-6, abs=1e-9 * abs(ref.bound)), info + " grad " + key
-    ctx.close()
+    ok, line, d = check_case(_draw(np.random.default_rng(1000 + case)))
+    assert ok, line
+    # beyond the shared rules: none of these 14 draws is in the chaotic regime, so they are held to the tight form outright
+    assert abs(d["res"].steps - d["ref"].steps) <= 1, line
+    assert d["e_b2"] < 1e-9, line
+
+
+def test_named_draw_weak_preconditioner_is_cg_chaos_not_a_kernel_defect():
+    """Sweep seed 2024, draw 169 (N=2398, D=26, M=7, RBF, fast level, tol 1): 31-32 steps with a 7-point preconditioner
+    (cond 6.6e3, top eigenvalue 1264 against 98).  The bound after the solve differed from the oracle's by 1.0e-4 relative while the
+    bound re-assembled at the GPU's own v agreed to 2e-15.  The oracle itself is not reproducible here: under an eps-sized perturbation
+    of its operator its bound moves by 5e-5 relative and its step count by one - asserted below, so that the acceptance of the GPU
+    result rests on a measurement, not on a comment."""
+    c = named_case(2024, 169)
+    assert (c["N"], c["D"], c["M"], c["kind"], c["prec"], c["tol"]) == (2398, 26, 7, "rbf", 1, 1.0)
+    ok, line, d = check_case(c)
+    assert ok, line
+    assert d["e_b2"] < 1e-12 and d["e_mv"] < 1e-12, line
+    from oracle import cglb_oracle as orc
+    X, y, Z = orc.synthetic_problem(c["N"], c["D"], c["M"], seed=c["data_seed"])
+    hyp = orc.Hypers(c["ls"], c["variance"], c["noise"], c["mean"], Z, 1e-6)
+    s = orc.roundoff_sensitivity(c["kind"], X, y, hyp, np.zeros(c["N"]), 1.0, 100, 40, delta=2.0 ** -52)
+    assert s.bound_spread > 1e-6 * abs(s.bound), "the oracle became reproducible on this draw: tighten the test"
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_named_draw_inducing_points_on_nearly_every_datum(precision):
+    """Sweep seed 2024, draw 186 (N=561, D=1, M=533, RBF): cond(K_uu) = 3e8.  The Z gradient is ~1e-11 of the bound and carries
+    cond * eps of absolute error in any implementation; the GPU's must stay within 10x the oracle's own floor under eps-level
+    perturbations of Z (oracle.grad_roundoff_spread), at both precision levels."""
+    c = named_case(2024, 186)
+    assert (c["N"], c["D"], c["M"], c["kind"]) == (561, 1, 533, "rbf")
+    c["prec"] = precision
+    ok, line, _ = check_case(c)
+    assert ok, line

@@ -1,54 +1,143 @@
 """Developer tool: randomized parity sweep of the HIP path against the dense numpy oracle (shapes off every tile grid).
-usage: python tools/fuzz_parity.py [cases] [seed] [fp32]"""
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from oracle import cglb_oracle as orc
-from cglb_amd.hip_context import HipContext
+usage: python tools/fuzz_parity.py [cases] [seed] [fp32]
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-fp32 = len(sys.argv) > 3 and sys.argv[3] == "fp32"
-td = torch.float32 if fp32 else torch.float64
-F = 3e6 if fp32 else 1.0   # tolerance factor of the fp32 run (round-off 1e-7 against 1e-16, with some slack for sums over N)
-bad = 0
-t0 = time.time()
-for c in range(cases):
+The acceptance rules are DERIVED, not tuned ("parity policy"):
+  * quantities that do not depend on the CG path are held to fixed tolerances: mat-vec 1e-11 of its largest entry, the bound
+    re-assembled by the oracle at the GPU's own v 1e-9, gradients 1e-6 of their largest entry;
+  * the CG path itself (step count, bound after the solve) must agree exactly / to north_star's 1e-6 - unless the oracle's OWN
+    answer moves under a perturbation of its operator of the size of the kernel-value accuracy of the precision level under test
+    (oracle.roundoff_sensitivity): then k = 4 times that measured spread is admissible for the bound, and a step difference is
+    admissible only if the stop statistic of the deciding iteration lies within its measured relative spread of the tolerance;
+  * a gradient block may deviate by k = 10 times its own noise floor under eps-level perturbations of Z and the lengthscales
+    (oracle.grad_roundoff_spread) when that is more than 1e-6 relative (ill-conditioned K_uu).
+`draw_case` / `check_case` are shared with tests/test_gpu_random_shapes.py (named draws of earlier sweeps)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+K_BOUND, K_GRAD = 4.0, 10.0
+KERNEL_DELTA = {0: 2.0 ** -52, 1: 1.0e-13}   # relative accuracy of the kernel values per precision level (include/cglb_hip.h "precision")
+
+
+def draw_case(rng, fp32=False):
+    """One draw of the sweep; consumes the generator in a fixed order so that (seed, index) names a case for good."""
     N = int(rng.choice([rng.integers(2, 300), rng.integers(300, 3000), rng.integers(3000, 9000)]))
     D = int(rng.integers(1, 33))
     M = int(min(N, rng.choice([rng.integers(1, 70), rng.integers(60, 200), rng.integers(200, 700)])))
     kind = str(rng.choice(["rbf", "matern32"]))
     prec = int(rng.integers(0, 2))
-    X, y, Z = orc.synthetic_problem(max(N, M, 8), D, M, seed=int(rng.integers(1 << 30)))
-    X, y = X[:N], y[:N]
+    data_seed = int(rng.integers(1 << 30))
     ls = rng.uniform(0.7, 2.5, size=D) * np.sqrt(D / 2.0)
-    hyp = orc.Hypers(ls, float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.1, 0.5) if fp32 else rng.uniform(0.02, 0.5)), float(rng.normal() * 0.1), Z, 1e-4 if fp32 else 1e-6)
+    variance = float(rng.uniform(0.5, 2.0))
+    noise = float(rng.uniform(0.1, 0.5) if fp32 else rng.uniform(0.02, 0.5))
+    mean = float(rng.normal() * 0.1)
     tol = float(rng.choice([1.0, 1e-2]))
+    p = rng.standard_normal(N)
+    return dict(N=N, D=D, M=M, kind=kind, prec=prec, data_seed=data_seed, ls=ls, variance=variance, noise=noise, mean=mean, tol=tol, p=p,
+                jitter=1e-4 if fp32 else 1e-6)
+
+
+def named_case(seed, index, fp32=False):
+    """Case `index` (0-based) of the sweep started with `seed`."""
+    rng = np.random.default_rng(seed)
+    for _ in range(index):
+        draw_case(rng, fp32)
+    return draw_case(rng, fp32)
+
+
+def check_case(c, fp32=False, options=None):
+    """Runs one case on the GPU and against the oracle.  Returns (ok, line, details)."""
+    import torch
+    from oracle import cglb_oracle as orc
+    from cglb_amd.hip_context import HipContext
+    td = torch.float32 if fp32 else torch.float64
+    F = 3e6 if fp32 else 1.0   # tolerance factor of the fp32 run (round-off 1e-7 against 1e-16, with some slack for sums over N)
+    N, D, M, kind, prec, tol = c["N"], c["D"], c["M"], c["kind"], c["prec"], c["tol"]
+    X, y, Z = orc.synthetic_problem(max(N, M, 8), D, M, seed=c["data_seed"])
+    X, y = X[:N], y[:N]
+    hyp = orc.Hypers(c["ls"], c["variance"], c["noise"], c["mean"], Z, c["jitter"])
     ctx = HipContext(X, y, M, kind, dtype=td)
     ctx.set_option("precision", prec)
+    for k, val in (options or {}).items():
+        ctx.set_option(k, val)
     ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
     v = torch.zeros(N, dtype=td, device=ctx.device)
     res = ctx.objective_and_grad(v, True, tol, 100, 40, with_grad=True)
-    ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, tol, 100, 40)
-    refg = orc.objective(kind, X, y, hyp, v.double().cpu().numpy(), run_cg=False, with_grad=True)
-    p = rng.standard_normal(N)
-    Ap = ctx.matvec(torch.from_numpy(p).to(td)).double().cpu().numpy()
-    Aref = orc.dense_cov(kind, X, hyp) @ p
+    cov = orc.dense_cov(kind, X, hyp)
+    ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, tol, 100, 40, cov=cov)
+    vh = v.double().cpu().numpy()
+    refg = orc.objective(kind, X, y, hyp, vh, run_cg=False, with_grad=True, cov=cov)
+    Ap = ctx.matvec(torch.from_numpy(c["p"]).to(td)).double().cpu().numpy()
+    ctx.close()
+    Aref = cov @ c["p"]
     e_mv = np.abs(Ap - Aref).max() / np.abs(Aref).max()
     e_b = abs(res.bound - ref.bound) / abs(ref.bound)
     e_b2 = abs(res.bound - refg.bound) / abs(refg.bound)      # same v: no CG-path dependence
-    gl = np.abs(res.grad["lengthscales"] - refg.grad["lengthscales"]).max() / (np.abs(refg.grad["lengthscales"]).max() + 1e-300)
-    gz = np.abs(res.grad["Z"] - refg.grad["Z"]).max() / (np.abs(refg.grad["Z"]).max() + 1e-300)
-    # the Z gradient carries cond(K_uu) eps of absolute error on both sides (M = N: K_uu as ill conditioned as K_ff): floor tied to the bound;
-    # two correct CG runs agree on the bound to 1e-6 or to a fraction of the stopping tolerance (the bound moves by 1/2 r^T P r <= tol
-    # between admissible stopping points and long solves with a weak preconditioner drift apart by round-off)
-    gz_abs = np.abs(res.grad["Z"] - refg.grad["Z"]).max()
-    ok = (e_mv < 1e-11 * F and e_b2 < 1e-9 * F and gl < 1e-6 * (3e3 if fp32 else 1) and (gz < 1e-6 * (3e3 if fp32 else 1) or gz_abs < 1e-9 * F * max(1.0, abs(ref.bound)))
-          and abs(res.steps - ref.steps) <= (3 if fp32 else 2)
-          and (e_b < 1e-6 * (1e3 if fp32 else 1) or abs(res.steps - ref.steps) > 0 or abs(res.bound - ref.bound) < 0.5 * tol))
-    bad += not ok
-    print(f"{'ok ' if ok else 'BAD'} N={N:5d} D={D:2d} M={M:3d} {kind:8s} prec={prec} tol={tol:g} steps {res.steps}/{ref.steps} matvec {e_mv:.1e} bound {e_b:.1e} "
-          f"bound@v {e_b2:.1e} grad ls {gl:.1e} Z {gz:.1e}", flush=True)
-    ctx.close()
-print(f"{cases} cases, {bad} bad, {time.time() - t0:.0f} s")
-sys.exit(1 if bad else 0)
+    why = []
+    if not e_mv < 1e-11 * F:
+        why.append("matvec")
+    if not e_b2 < 1e-9 * F:
+        why.append("bound@v")
+    # ---- CG path: exact unless the oracle itself is not reproducible at the kernel-accuracy level
+    dsteps = abs(res.steps - ref.steps)
+    sens = None
+    if dsteps > 0 or not e_b < 1e-6 * (1e3 if fp32 else 1):
+        delta = 1.2e-7 if fp32 else KERNEL_DELTA[prec]
+        sens = orc.roundoff_sensitivity(kind, X, y, hyp, np.zeros(N), tol, 100, 40, delta=delta, cov=cov)
+        if dsteps > 0:
+            # the two runs part at iteration k = min(steps): one read a statistic <= tol there, the other did not.  Admissible only if
+            # the oracle's statistic at k is within its own measured relative spread (x K_BOUND) of the tolerance.
+            k = min(res.steps, ref.steps)
+            gap = abs(sens.history[k] - tol) / tol if k < len(sens.history) else np.inf
+            if dsteps > 1 + sens.steps_spread or not gap <= K_BOUND * sens.stat_rel_spread[min(k, len(sens.stat_rel_spread) - 1)]:
+                why.append(f"steps (gap {gap:.1e} spread {sens.stat_rel_spread[min(k, len(sens.stat_rel_spread) - 1)]:.1e})")
+            # a different stopping point moves the bound by at most the stop statistic of the earlier one
+            if abs(res.bound - ref.bound) > K_BOUND * sens.bound_spread + 1.001 * sens.history[k]:
+                why.append("bound after a different step count")
+        elif abs(res.bound - ref.bound) > K_BOUND * sens.bound_spread:
+            why.append(f"bound (oracle spread {sens.bound_spread:.1e})")
+    # ---- gradients at the GPU's v
+    w = None
+    gerr = {}
+    for key in ("lengthscales", "Z", "variance", "noise", "mean"):
+        a, b = np.asarray(res.grad[key]), np.asarray(refg.grad[key])
+        scale = np.abs(b).max() + 1e-300
+        gerr[key] = float(np.abs(a - b).max() / scale)
+        if gerr[key] < 1e-6 * (3e3 if fp32 else 1):
+            continue
+        if key in ("variance", "noise", "mean") and np.abs(a - b).max() < 1e-9 * F * abs(ref.bound):
+            continue  # a scalar derivative that cancels to ~0 against terms of the size of the bound
+        if w is None:
+            terms = orc.common_terms(kind, X, hyp)
+            r = (y - hyp.mean) - cov @ vh
+            w, _ = orc.nystrom_precond(terms.A, terms.LB, hyp.noise, r)
+            floor = orc.grad_roundoff_spread(kind, X, hyp, vh, w)
+        if np.abs(a - b).max() > K_GRAD * F * floor[key]:
+            why.append(f"grad {key} ({np.abs(a - b).max():.1e} abs, floor {floor[key]:.1e})")
+    ok = not why
+    line = (f"{'ok ' if ok else 'BAD'} N={N:5d} D={D:2d} M={M:3d} {kind:8s} prec={prec} tol={tol:g} steps {res.steps}/{ref.steps} matvec {e_mv:.1e} "
+            f"bound {e_b:.1e} bound@v {e_b2:.1e} grad ls {gerr['lengthscales']:.1e} Z {gerr['Z']:.1e}"
+            + (f" [oracle spread: bound {sens.bound_spread / abs(ref.bound):.1e} rel, steps {sens.steps_spread}]" if sens else "")
+            + ("  <- " + "; ".join(why) if why else ""))
+    return ok, line, dict(res=res, ref=ref, refg=refg, sens=sens, gerr=gerr, e_mv=e_mv, e_b=e_b, e_b2=e_b2)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    fp32 = len(sys.argv) > 3 and sys.argv[3] == "fp32"
+    bad = 0
+    t0 = time.time()
+    for _ in range(cases):
+        ok, line, _d = check_case(draw_case(rng, fp32), fp32)
+        bad += not ok
+        print(line, flush=True)
+    print(f"{cases} cases, {bad} bad, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

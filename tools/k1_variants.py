@@ -2,7 +2,12 @@
 EXTRA_DEFS) on one box: pair-kernel time of the K_ff mat-vec and of the gradient pass, and the deviation of the mat-vec from the
 first library given (the reference build) and from the blocked C oracle on a row sample.
 
+  tools/build_variant.sh d3 "-DCGLB_EXP_DEG=3"         # one object directory per variant, built from clean
   python tools/k1_variants.py cglb_amd/lib/libcglb_hip.so cglb_amd/lib/variants/libcglb_d3.so ...
+
+Variant libraries must come from tools/build_variant.sh (it leaves libcglb_NAME.defs beside the library): a variant linked from
+an object directory shared with other define sets can mix objects - round 2 lost a variant to a GPU memory access fault that way
+(profiles/r02_k1_variants.log).
 """
 import json
 import os
@@ -41,6 +46,12 @@ print("RESULT " + json.dumps(out))
 
 def main():
     libs = [os.path.abspath(a) for a in sys.argv[1:]]
+    for lib in libs:
+        name = os.path.basename(lib)
+        if name == "libcglb_hip.so":
+            continue  # the product build (cglb_amd/csrc/Makefile defaults, its own object directory)
+        if not os.path.exists(lib[:-len(".so")] + ".defs"):
+            raise SystemExit(f"{name}: no {name[:-3]}.defs beside it - build variants with tools/build_variant.sh (clean per-variant object directory)")
     outdir = os.path.join(ROOT, "gpurun_out", "k1_variants")
     os.makedirs(outdir, exist_ok=True)
     rounds = int(os.environ.get("ROUNDS", 2))
