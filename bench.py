@@ -82,6 +82,54 @@ def cpu_baseline(kind, X, y, Z, hyp, N, D, M, steps_cg, restarts):
     }
 
 
+def training_secondary(X, y, Z, hyp, kind, iters=30):
+    """The reference's REAL workload (pytorch/interface.py:445-543; xpert-main.toml: 2 000 L-BFGS-B steps): warm-started evaluations
+    through the backend mirror.  `iters` SciPy L-BFGS-B iterations from the headline hypers with Z as given (the greedy selection is
+    not part of the loop); reports wall time per evaluation, the mean CG step count, and where the device time of an evaluation goes
+    (HIP events inside cglb_objective_and_grad, cglb_set_option "eval_profile")."""
+    import tempfile
+    from cglb_amd.backend import interface
+    from cglb_amd.backend.callbacks import Logger
+    from cglb_amd.backend.models import CGLB, BaseKernel, GaussianLikelihood, InducingPointKernel, ScaleKernel
+    D = X.shape[1]
+    base = BaseKernel(kind, ard_num_dims=D)
+    base.lengthscale = hyp["lengthscales"]
+    scale = ScaleKernel(base)
+    scale.outputscale = hyp["variance"]
+    lik = GaussianLikelihood(lower_bound=1e-6)
+    lik.noise = hyp["noise"]
+    model = CGLB((X, y), lik, InducingPointKernel(scale, Z))
+    tmp = tempfile.mkdtemp(prefix="cglb_bench_")
+    logger = Logger(tmp, lambda: {}, lambda: {}, holdout_interval=-1, include_feval_log=True, verbose=False)
+    hip = model.hip
+    walls = []
+    orig = hip.objective_and_grad
+
+    def timed(*a, **k):
+        t = time.perf_counter()
+        r = orig(*a, **k)
+        walls.append(1e3 * (time.perf_counter() - t))
+        return r
+    hip.objective_and_grad = timed
+    hip.set_option("eval_profile", 1)      # the warm-up evaluation of optimize() is inside: dropped from the host-side medians below
+    t0 = time.perf_counter()
+    results = interface.optimize(model, ((X, y), (X[:8], y[:8])), iters, logger, "scipy")
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    n = hip.get_stat("eval_count")
+    phases = {k: hip.get_stat(f"eval_{k}_ms") / max(n, 1.0) for k in ("setup", "pcg", "final", "grad")}
+    hip.set_option("eval_profile", 0)
+    steps = np.asarray(logger.logs["steps-per-feval"], dtype=np.float64)
+    nfev, nit = int(sum(r.nfev for r in results)), int(sum(r.nit for r in results))
+    out = {"workload": f"{nit} L-BFGS-B iterations / {nfev} warm-started evaluations through cglb_amd.backend.optimize, same shape and start hypers",
+           "ms_per_evaluation_wall": 1e3 * wall / max(nfev + 1, 1), "ms_per_evaluation_c_abi_median": float(np.median(walls[1:])),
+           "mean_cg_steps": float(steps.mean()), "max_cg_steps": float(steps.max()),
+           "device_ms_per_evaluation": phases, "device_ms_step_independent": phases["setup"] + phases["final"] + phases["grad"],
+           "evaluations": nfev, "iterations": nit, "final_loss": float(results[-1].fun), "L_diag_ratio": hip.get_stat("L_diag_ratio")}
+    hip.close()
+    return out
+
+
 def check_against_fixture(N, D, M, kind, hyp_name, res, steps=None, bound=None):
     """Compare steps / bound of a cold-start evaluation with tests/golden/headline/*.npz (data, not oracle code).  north_star: 1e-6
     relative on the bound; step count exact up to 40 steps, +-1 beyond (DESIGN.md section 6 note).  Raises on a mismatch."""
@@ -165,10 +213,30 @@ def main():
     cg = dict(max_error=1.0, max_cg_iter=100, restart_cg_iter=40)  # conjugate_gradient.py:37-39
 
     per, parts = row_partition(N, world)
-    ctx = HipContext(X, y, M, kind, device=dev, row_range=parts[rank])
     comm = Comm(force=force_dist)
-    # N > 1: cyclic-symmetric scheme (each kernel value used twice, global upper triangle dealt to the ranks by 256-row blocks)
-    drv = SymShardedCGLB(HipSymLocalOps(ctx), comm) if use_dist else None
+    # N > 1: cyclic-symmetric scheme (each kernel value used twice, global upper triangle dealt to the ranks by 256-row blocks).
+    # Default driver: the loops INSIDE the library with RCCL on the context stream (cglb_dist_*, cglb_amd/dist_context.py) - one host
+    # round trip per PCG iteration.  CGLB_BENCH_DRIVER=python selects the host-driven twin (torch.distributed collectives between the
+    # C calls); if the in-library communicator cannot be created the bench falls back to it and says so in the record.
+    driver = os.environ.get("CGLB_BENCH_DRIVER", "native") if use_dist else "fused"
+    driver_note = None
+    ctx = drv = None
+    if driver == "native":
+        try:
+            from cglb_amd.dist_context import DistHipContext
+            ctx = DistHipContext(X, y, M, kind, device=dev, collectives="rccl" if backend == "nccl" else "callbacks", force=force_dist)
+        except Exception as exc:  # noqa: BLE001 - any failure to set the communicator up: use the host-driven twin, keep the reason
+            driver_note = f"native driver unavailable ({type(exc).__name__}: {exc}); host-driven twin used"
+            driver, ctx = "python", None
+        ok = torch.tensor([1.0 if driver == "native" else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                 # all ranks take the same driver
+        if float(ok.item()) == 0.0 and driver == "native":
+            ctx.close()
+            driver, ctx, driver_note = "python", None, "native driver unavailable on another rank; host-driven twin used"
+    if ctx is None:
+        ctx = HipContext(X, y, M, kind, device=dev, row_range=parts[rank])
+        if use_dist:
+            drv = SymShardedCGLB(HipSymLocalOps(ctx), comm)
     v = torch.zeros(N, dtype=torch.float64, device=dev)
 
     def barrier():
@@ -178,7 +246,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     def one_step():
-        if not use_dist:
+        if drv is None:   # single GPU (fused C call) or N ranks with the loops inside the library: same call, full replicated v
             v.zero_()
             return ctx.objective_and_grad(v, True, cg["max_error"], cg["max_cg_iter"], cg["restart_cg_iter"], with_grad=True)
         drv.v.zero_()
@@ -236,12 +304,17 @@ def main():
                                      "k1_ms": ctx_m.time_kernel(3, 5)}
             ctx_m.close()
             del ctx_m, vm
+        if not use_dist:
+            secondary["training"] = training_secondary(X, y, Z, hypers[args.hypers], kind)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the library's stream -------------
-    ctx.setup_local()
-    if use_dist:
-        comm.allreduce(ctx.aat_tensor())
-    ctx.setup_finish()
+    if driver == "native":
+        ctx.setup()
+    else:
+        ctx.setup_local()
+        if use_dist:
+            comm.allreduce(ctx.aat_tensor())
+        ctx.setup_finish()
     reps = 10
     # dominant kernel: average duration of its launches INSIDE the timed region (HIP events on the library's stream, rank 0's share
     # of the triangle when N > 1); the stand-alone figure (back-to-back launches outside the solver) is kept beside it
@@ -346,8 +419,11 @@ def main():
             "config": {
                 "workload": f"CGLB objective+gradient, synthetic N={N} D={D} M={M} {kind} fp64, hypers={args.hypers}, cold start v=0",
                 "N": N, "D": D, "M": M, "kernel": kind, "hypers": {k: (np.asarray(val).tolist()) for k, val in hypers[args.hypers].items()},
-                "cg": cg, "parallelism": f"cyclic-symmetric K_ff blocks + column-sharded Nystrom panel x{world}" if world > 1 else "single GPU",
+                "cg": cg, "parallelism": (f"cyclic-symmetric K_ff blocks + column-sharded Nystrom panel x{world}, "
+                                f"{'loops and RCCL collectives inside libcglb_hip.so' if driver == 'native' else 'host-driven collectives (torch.distributed)'}")
+                if world > 1 else "single GPU",
             },
+            "driver": driver, "driver_note": driver_note,
             "cg_steps": res.steps, "cg_residual_error": res.residual_error, "bound": res.bound,
             "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_grad": roofline_grad, "cpu_baseline": cpu, "secondary": secondary,
             "parity_check": parity,

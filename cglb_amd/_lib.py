@@ -13,7 +13,11 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_void_p
 
 import torch  # noqa: F401  (must precede the dlopen below, see module docstring)
 
-OK, ERR_BAD_ARG, ERR_NOT_PD, ERR_HIP, ERR_BLAS, ERR_STATE = range(6)
+OK, ERR_BAD_ARG, ERR_NOT_PD, ERR_HIP, ERR_BLAS, ERR_STATE, ERR_COMM = range(7)
+COMM_ID_BYTES = 128
+#: collective callbacks of cglb_comm_init_callbacks: (user, buf, count, dtype, stream) -> 0 on success
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p)
 RBF, MATERN32 = 0, 1
 F64, F32 = 0, 1
 
@@ -66,6 +70,19 @@ SIGNATURES = {
     "cglb_shard_obj_w": (c_int, [c_void_p, c_void_p]),
     "cglb_shard_obj_phase3_cyclic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cglb_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "cglb_shard_predict_u": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "cglb_shard_predict_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "cglb_comm_get_unique_id": (c_int, [c_void_p]),
+    "cglb_comm_init_rccl": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "cglb_comm_init_callbacks": (c_int, [c_void_p, c_int, c_int, ALLREDUCE_FN, ALLGATHER_FN, c_void_p]),
+    "cglb_comm_destroy": (c_int, [c_void_p]),
+    "cglb_dist_setup": (c_int, [c_void_p]),
+    "cglb_dist_matvec": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "cglb_dist_precond_apply": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
+    "cglb_dist_pcg_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int, c_int, POINTER(c_int), POINTER(c_double)]),
+    "cglb_dist_objective_and_grad": (c_int, [c_void_p, c_void_p, c_int, c_double, c_int, c_int, POINTER(c_double), POINTER(c_double),
+                                             POINTER(c_int), POINTER(c_double)]),
+    "cglb_dist_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cglb_get_stat": (c_int, [c_void_p, c_char_p, POINTER(c_double)]),
     "cglb_select_inducing": (c_int, [c_void_p, POINTER(c_double), c_double, c_double, POINTER(c_int64), c_void_p, POINTER(c_double)]),
     "cglb_get_matrix": (c_int, [c_void_p, c_int, c_void_p]),
@@ -114,4 +131,6 @@ def check(rc: int, ctx=None) -> None:
         raise RuntimeError(f"cglb_hip: {msg}")
     if rc == ERR_STATE:
         raise RuntimeError(f"cglb_hip: call order: {msg}")
+    if rc == ERR_COMM:
+        raise RuntimeError(f"cglb_hip: collective: {msg}")
     raise RuntimeError(f"cglb_hip: error {rc}: {msg}")

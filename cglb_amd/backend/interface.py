@@ -191,7 +191,25 @@ def _create_model_cglb(model_cfg: CGLBConfig, data: Data):
     extra = {}
     if _STATE["config_semantics"] == "tf":  # the TF twin's create_model hands these to the model (tensorflow/interface.py:244-258)
         extra = dict(max_error=model_cfg.max_error, joint_optimization=model_cfg.joint_optimization, vzero=model_cfg.vzero)
-    return CGLB((np.asarray(data[0]), np.asarray(data[1]).reshape(-1)), likelihood, kernel, dtype=_STATE["dtype"], **extra)
+    model = CGLB((np.asarray(data[0]), np.asarray(data[1]).reshape(-1)), likelihood, kernel, dtype=_STATE["dtype"], **extra)
+    _broadcast_parameters(model)
+    return model
+
+
+def _broadcast_parameters(model: CGLB):
+    """N ranks: every rank built the model from the same data and config (the greedy inducing-point selection is deterministic); the
+    initial parameters are broadcast from rank 0 all the same, so that the replicas start from identical bits by construction."""
+    ctx = model.hip
+    if getattr(ctx, "world", 1) <= 1:
+        return
+    import torch.distributed as dist
+    group = getattr(ctx, "group", None)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    with torch.no_grad():
+        for p in model.parameters():
+            buf = p.detach().to(ctx.device).contiguous()
+            dist.broadcast(buf, src=src, group=group)
+            p.copy_(buf.to(p.device))
 
 
 @contextmanager
@@ -208,13 +226,24 @@ def _narrow_host_pools():
     torch.set_num_threads(min(prev, n))
     try:
         try:
-            from threadpoolctl import threadpool_limits
+            from threadpoolctl import threadpool_info, threadpool_limits
         except Exception:  # pragma: no cover
             threadpool_limits = None
         if threadpool_limits is None:
             yield
         else:
-            with threadpool_limits(limits=n):
+            # only ever NARROW a pool: a launcher may have set OMP_NUM_THREADS=1 (torch.distributed.run does), and widening a BLAS pool
+            # beyond the width it was initialised with crashed SciPy's L-BFGS-B core (SIGSEGV inside _lbfgsb.setulb on both ranks of the
+            # first CLI run under torch.distributed.run, round 3)
+            limits = {}
+            for info in threadpool_info():
+                api, cur = info.get("user_api"), int(info.get("num_threads") or 1)
+                if api and cur > n:
+                    limits[api] = n
+            if limits:
+                with threadpool_limits(limits=limits):
+                    yield
+            else:
                 yield
     finally:
         torch.set_num_threads(prev)
@@ -224,6 +253,28 @@ def _narrow_host_pools():
 def _optimize_cglb(model: CGLB, dataset, num_steps: int, logger: Logger, optimize: str = "scipy"):
     with _narrow_host_pools():
         return _optimize_cglb_impl(model, dataset, num_steps, logger, optimize)
+
+
+def _assert_ranks_agree(model: CGLB, what: str):
+    """N ranks each run the reference's single-process optimiser on what must be identical (loss, gradient) sequences: the loss of the
+    last evaluation and a checksum of the parameters are all-gathered once per round; a rank that drifted raises on EVERY rank (all
+    see the same gathered numbers), instead of the job running on with replicas that no longer describe one model."""
+    ctx = model.hip
+    if getattr(ctx, "world", 1) <= 1:
+        return
+    import torch.distributed as dist
+    digest = 0.0
+    for p in model.parameters():
+        digest += float(p.detach().double().abs().sum())
+    mine = torch.tensor([float(model.last_bound), digest], dtype=torch.float64, device=ctx.device)
+    group = getattr(ctx, "group", None)
+    if group is None and getattr(ctx, "comm", None) is not None:
+        group = ctx.comm.group
+    gathered = [torch.empty_like(mine) for _ in range(ctx.world)]
+    dist.all_gather(gathered, mine, group=group)
+    vals = torch.stack(gathered).cpu().numpy()
+    if not (np.all(vals[:, 0] == vals[0, 0]) and np.all(vals[:, 1] == vals[0, 1])):
+        raise RuntimeError(f"ranks disagree {what}: (bound, parameter checksum) per rank = {vals.tolist()}")
 
 
 def _optimize_cglb_impl(model: CGLB, dataset, num_steps: int, logger: Logger, optimize: str = "scipy"):
@@ -268,6 +319,7 @@ def _optimize_cglb_impl(model: CGLB, dataset, num_steps: int, logger: Logger, op
         result = optimize_fn(params, remaining)
         remaining -= result.nit
         results.append(result)
+        _assert_ranks_agree(model, f"after optimisation round {round_id}")
     return results
 
 

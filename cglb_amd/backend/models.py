@@ -20,6 +20,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from ..dist_context import make_context
 from ..hip_context import HipContext
 from .conjugate_gradient import ConjugateGradient, ConjugateGradientStats, KernelOperator, NystromPreconditioner
 
@@ -147,8 +148,12 @@ class CGLB(SGPR):
 
     def __init__(self, data: Data, likelihood: GaussianLikelihood, kernel: InducingPointKernel, dtype: torch.dtype = torch.float64,
                  device: Optional[torch.device] = None, max_error: Optional[float] = None, joint_optimization: bool = False,
-                 vzero: bool = False):
-        """The last three arguments are the TF twin's (tensorflow/models.py:31-51): the torch reference never passes them
+                 vzero: bool = False, context=None):
+        """`context`: the engine behind the model - by default `make_context` builds it: a `HipContext` in a single-process run, one rank
+        of a `DistHipContext` (rows of K_ff dealt over the ranks, collectives inside libcglb_hip.so) when a torch.distributed process
+        group with more than one rank is initialised; every rank then holds the full replicated `v_vec` and evaluates identical
+        (loss, gradient) pairs.  Tests inject `distributed.PyDistContext` here.
+        The three arguments before it are the TF twin's (tensorflow/models.py:31-51): the torch reference never passes them
         (pytorch/interface.py:315-323) and neither does `create_model` unless `configure_backend(config_semantics="tf")`.
         `max_error` becomes the default tolerance of `LowerBoundCG`; `joint_optimization` (without `vzero`) makes `v_vec` a trainable
         parameter and skips CG; `vzero` keeps v = 0 and skips CG (tensorflow/models.py:161-164)."""
@@ -156,7 +161,11 @@ class CGLB(SGPR):
         self.dtype = dtype
         self.max_error, self.joint_optimization, self.vzero = max_error, bool(joint_optimization), bool(vzero)
         kind = kernel.base_kernel.base_kernel.kind
-        self.hip = HipContext(self.train_inputs[0], self.train_targets, kernel.inducing_points.shape[0], kind, dtype=dtype, device=device)
+        if context is None:
+            context = make_context(self.train_inputs[0], self.train_targets, kernel.inducing_points.shape[0], kind, dtype=dtype, device=device)
+        self.hip = context
+        if getattr(context, "world", 1) > 1 and self.joint_optimization and not self.vzero:
+            raise NotImplementedError("joint optimisation of v (the TF twin's opt-in) is not available on more than one rank")
         v0 = self._build_v_vec()
         # v0 trainable only under joint optimisation (tensorflow/models.py:47-48); otherwise a plain buffer without grad (models.py:59-68)
         self._v_vec = nn.Parameter(v0) if (self.joint_optimization and not self.vzero) else v0

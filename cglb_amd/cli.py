@@ -9,6 +9,14 @@ Same option letters as cli.py:60-65, :141-152, :207-216; writes model.json / res
 (datasets.py:47-76; no network here), so DATASET is either `synthetic-N-D` (e.g. synthetic-2000-3, the generator of
 cglb_amd/data.py) / `snelson-like` (N=200, D=1 stand-in for snelson1d), or a path to an .npz with arrays X, y; all are
 z-normalised and split 67/33 with the seed, as datasets.py:35-39,:60-70 does.
+
+N GPUs of one node (BASELINE config C4, "full CGLB train loop" on 8 x MI355X): launch the same command line under torch.distributed.run,
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P -m cglb_amd.cli -b hip ... train ...
+
+one process per GPU (LOCAL_RANK picks the device).  Every rank builds the same model on the same data, owns 1/N of the rows of K_ff and
+of the Nystrom panel (cglb_amd/dist_context.py) and runs the same optimiser on identical (loss, gradient) pairs; rank 0 alone writes
+model.json / results.json / logs.json and prints the result line.
 """
 from __future__ import annotations
 
@@ -83,15 +91,17 @@ def create_optimize_fn(backend, dataset: DatasetBundle, logdir: str, num_steps: 
         datasets = dataset.to_tuple()
         metrics_fn = backend.metrics_fn(model, datasets)
         logger = Logger(logdir, metrics_fn, lambda: backend.model_parameters(model), 20, include_feval_log=True)
+        logger.verbose = logger.verbose and _rank() == 0
         backend.optimize(model, datasets, num_steps, logger, optimizer)
-        backend.save(model, logdir)
-        logs, results = logger.logs, metrics_fn()
+        logs, results = logger.logs, metrics_fn()           # collective on N ranks: every rank evaluates the metrics
         results["id"] = logdir
         logs["id"] = logdir
-        with open(Path(logdir, "results.json"), "w") as f:   # cli.py:105-109: json_tricks.dump -> same encoding (backend/jsonio.py)
-            jsonio.dump(results, f)
-        with open(Path(logdir, "logs.json"), "w") as f:
-            jsonio.dump(logs, f)
+        if _rank() == 0:
+            backend.save(model, logdir)
+            with open(Path(logdir, "results.json"), "w") as f:   # cli.py:105-109: json_tricks.dump -> same encoding (backend/jsonio.py)
+                jsonio.dump(results, f)
+            with open(Path(logdir, "logs.json"), "w") as f:
+                jsonio.dump(logs, f)
         return results
 
     return optimize_fn
@@ -103,10 +113,36 @@ def create_metric_fn(backend, dataset: DatasetBundle, destination: Path) -> Call
     def metric_fn(model):
         results = backend.metrics_fn(model, dataset.to_tuple())()
         results["id"] = str(destination.parent)
-        np.save(destination, results)
+        if _rank() == 0:
+            np.save(destination, results)
         return results
 
     return metric_fn
+
+
+def _rank() -> int:
+    return int(os.environ.get("RANK", "0"))
+
+
+def _init_distributed():
+    """Under torch.distributed.run (WORLD_SIZE > 1): one process per GPU, process group over RCCL ("nccl" is RCCL on ROCm).
+    CGLB_DIST_BACKEND=gloo and CGLB_SHARE_GPU=1 are rehearsal knobs for a one-GPU box (several ranks on cuda:0, collectives through
+    the callback provider of the library)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return
+    import torch
+    import torch.distributed as dist
+    from datetime import timedelta
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    local = 0 if os.environ.get("CGLB_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    backend = os.environ.get("CGLB_DIST_BACKEND", "nccl")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=timedelta(minutes=5))
+        else:
+            dist.init_process_group(backend, timeout=timedelta(minutes=5))
 
 
 @click.group()
@@ -119,6 +155,7 @@ def create_metric_fn(backend, dataset: DatasetBundle, destination: Path) -> Call
 def main(ctx, backend, float_type, logdir, seed, keops):
     logdir_path = Path(logdir).expanduser().resolve()
     logdir_path.mkdir(exist_ok=True, parents=True)
+    _init_distributed()
     be = BACKENDS[backend]
     be.configure_backend(logdir=str(logdir_path), keops=keops)
     be.set_default_float(float_type)
@@ -166,7 +203,8 @@ def _cglb_command(group):
         if param_file:
             model = o["backend"].load(model, param_file)
         results = o["callback"](model)
-        click.echo(json.dumps(_jsonable(results)))
+        if _rank() == 0:
+            click.echo(json.dumps(_jsonable(results)))
 
     return cglb
 

@@ -5,6 +5,8 @@
 #include <cstring>
 #include <new>
 
+#include <rccl/rccl.h>
+
 #include "devmath.h"
 #include "dispatch.h"
 
@@ -13,7 +15,7 @@ namespace {
 thread_local std::string g_create_error;
 
 // scalar slots in ctx->scal
-enum { S_RZ = 0, S_PAP = 1, S_NRZ = 2, S_TRACE = 3, S_SUMLOG = 4, S_TRBINV = 5, S_TMP = 6, S_SC = 8, S_TMP2 = 16 };
+enum { S_RZ = 0, S_PAP = 1, S_NRZ = 2, S_TRACE = 3, S_SUMLOG = 4, S_TRBINV = 5, S_TMP = 6, S_SC = 8, S_TMP2 = 16, S_LDIAG = 56 };
 
 // ---- typed rocBLAS / rocSOLVER wrappers ---------------------------------------------------------------
 inline rocblas_status xpotrf(rocblas_handle h, rocblas_fill u, int n, double* A, int lda, rocblas_int* info) { return rocsolver_dpotrf(h, u, n, A, lda, info); }
@@ -179,9 +181,12 @@ int setup_local_impl(cglb_ctx* c) {
     if (c->chol_mode == 1) CGLB_TRY(launch_cholesky_lower(c, c->Lc, (int*)c->info_dev));  // blocked LDS Cholesky (kernels_chol.hip)
     else BLAS_CHECK(c, xpotrf(c->blas, rocblas_fill_lower, M, (T*)c->Lc, M, c->info_dev));
     rocblas_int info = 0;
+    double ldiag[2] = {1.0, 1.0};
+    CGLB_TRY(launch_diag_minmax(c, c->Lc, c->scal + S_LDIAG));   // rides on the read-back of the factorisation status
     HIP_CHECK(c, hipMemcpyAsync(&info, c->info_dev, sizeof(info), hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    CGLB_TRY(read_scalars(c, c->scal + S_LDIAG, ldiag, 2));
     if (info != 0) return cglb_fail(c, CGLB_ERR_NOT_PD, "cholesky(K_uu + jitter I) failed: leading minor " + std::to_string(info) + " not positive definite");
+    c->L_diag_ratio = ldiag[0] > 0.0 ? ldiag[1] / ldiag[0] : 1.0e300;
     CGLB_TRY(launch_tri_clean(c, c->Lc, 1));
     if (c->precond_mode == 1) {  // explicit L^-1 in both orientations for the implicit preconditioner
         HIP_CHECK(c, hipMemcpyAsync(c->Linv, c->Lc, (size_t)M * M * c->esz, hipMemcpyDeviceToDevice, c->stream));
@@ -419,7 +424,7 @@ int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const voi
                         &zero, (T*)c->Mtmp, M));
     hipLaunchKernelGGL((trace_kernel<T>), dim3(1), dim3(256), 0, c->stream, (const T*)c->Mtmp, M, c->scal + S_TRBINV);
     // c = Kuu^-1 Kuf w = sigma L^-T (A w); mhalf = -c/2
-    const bool use_inv = c->grad_trsm == 0;
+    const bool use_inv = c->grad_trsm == 0 || (c->grad_trsm == 2 && c->L_diag_ratio <= CGLB_LINV_DIAG_RATIO);
     if (use_inv) {
         CGLB_TRY(ensure_Linv<T>(c));
         if (!c->Mtmp3) CGLB_TRY(dalloc(c, &c->Mtmp3, (size_t)M * M * c->esz));
@@ -510,6 +515,205 @@ int obj_finish(cglb_ctx* c, const double* sc_dev, double* out4) {
     return CGLB_OK;
 }
 
+
+// ================================ N ranks inside the library (include/cglb_hip.h, "N ranks inside the library") ================================
+// Same scheme as cglb_amd/distributed.py: SymShardedCGLB (the host-driven twin that the gloo tests exercise with CPU local ops): the global
+// upper triangle of K_ff dealt to the ranks by cyclic row blocks, replicated full-length p, Ap, v, r, b, the Nystrom panel column-sharded over
+// contiguous rows, three collectives per PCG iteration - issued here on the context stream.
+// ---- phase timing of an evaluation (option "eval_profile") -------------------------------------------------------------------
+int eval_mark(cglb_ctx* c) {
+    if (!c->eval_profile) return CGLB_OK;
+    if (c->eval_events_used >= c->eval_events.size()) {
+        hipEvent_t ev;
+        HIP_CHECK(c, hipEventCreate(&ev));
+        c->eval_events.push_back(ev);
+    }
+    HIP_CHECK(c, hipEventRecord(c->eval_events[c->eval_events_used++], c->stream));
+    return CGLB_OK;
+}
+int eval_collect(cglb_ctx* c) {
+    for (size_t q = 0; q + 5 <= c->eval_events_used; q += 5) {
+        HIP_CHECK(c, hipEventSynchronize(c->eval_events[q + 4]));
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0.f;
+            HIP_CHECK(c, hipEventElapsedTime(&ms, c->eval_events[q + k], c->eval_events[q + k + 1]));
+            c->eval_ms[k] += ms;
+        }
+        c->eval_count += 1;
+    }
+    c->eval_events_used = 0;
+    return CGLB_OK;
+}
+
+inline ncclDataType_t nccl_type(const cglb_ctx* c, bool as_double) { return (as_double || c->dtype == CGLB_F64) ? ncclDouble : ncclFloat; }
+
+int require_comm(cglb_ctx* c) {
+    if (!c->comm) return cglb_fail(c, CGLB_ERR_STATE, "no communicator: call cglb_comm_init_rccl or cglb_comm_init_callbacks first");
+    if (c->precond_mode != 0) return cglb_fail(c, CGLB_ERR_STATE, "the N-rank path needs the stored-panel preconditioner (precond_mode 0)");
+    return CGLB_OK;
+}
+
+int comm_fail(cglb_ctx* c, const char* what, int code) { return cglb_fail(c, CGLB_ERR_COMM, std::string(what) + " failed with code " + std::to_string(code)); }
+
+// in-place sum over ranks of `count` elements (vector element type, or double when as_double)
+int comm_allreduce(cglb_ctx* c, void* buf, int64_t count, bool as_double = false) {
+    cglb_comm_state* m = c->comm;
+    m->n_allreduce++;
+    if (m->kind == 1) {
+        const ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, nccl_type(c, as_double), ncclSum, (ncclComm_t)m->nccl, c->stream);
+        if (r != ncclSuccess) return cglb_fail(c, CGLB_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+        return CGLB_OK;
+    }
+    const int rc = m->ar(m->user, buf, count, as_double ? CGLB_F64 : c->dtype, (void*)c->stream);
+    return rc == 0 ? CGLB_OK : comm_fail(c, "all-reduce callback", rc);
+}
+
+// in-place all-gather: rank g's `count` elements sit at element g * count of buf
+int comm_allgather(cglb_ctx* c, void* buf, int64_t count) {
+    cglb_comm_state* m = c->comm;
+    m->n_allgather++;
+    if (m->kind == 1) {
+        const char* mine = (const char*)buf + (size_t)m->rank * (size_t)count * c->esz;
+        const ncclResult_t r = ncclAllGather(mine, buf, (size_t)count, nccl_type(c, false), (ncclComm_t)m->nccl, c->stream);
+        if (r != ncclSuccess) return cglb_fail(c, CGLB_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+        return CGLB_OK;
+    }
+    const int rc = m->ag(m->user, buf, count, c->dtype, (void*)c->stream);
+    return rc == 0 ? CGLB_OK : comm_fail(c, "all-gather callback", rc);
+}
+
+void comm_free(cglb_ctx* c) {
+    cglb_comm_state* m = c->comm;
+    if (!m) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
+    if (m->kind == 1 && m->nccl) (void)ncclCommDestroy((ncclComm_t)m->nccl);
+    void* ptrs[] = {m->p, m->r, m->Ap, m->Kv, m->b, m->zseg, m->ubuf, m->u, m->aw, m->sc, m->grad, m->gat};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    delete m;
+    c->comm = nullptr;
+}
+
+int comm_alloc(cglb_ctx* c, int world, int rank) {
+    if (world < 1 || rank < 0 || rank >= world) return cglb_fail(c, CGLB_ERR_BAD_ARG, "bad world/rank");
+    const int64_t per = (c->N + world - 1) / world;
+    const int64_t r0 = std::min<int64_t>((int64_t)rank * per, c->N), r1 = std::min<int64_t>((int64_t)(rank + 1) * per, c->N);
+    if (c->r0 != r0 || c->r1 != r1)
+        return cglb_fail(c, CGLB_ERR_BAD_ARG, "the context owns rows [" + std::to_string(c->r0) + "," + std::to_string(c->r1) + ") but rank " + std::to_string(rank) + " of " +
+                                                  std::to_string(world) + " must own [" + std::to_string(r0) + "," + std::to_string(r1) + ")");
+    comm_free(c);
+    cglb_comm_state* m = new (std::nothrow) cglb_comm_state();
+    if (!m) return cglb_fail(c, CGLB_ERR_BAD_ARG, "out of host memory");
+    c->comm = m;
+    m->world = world; m->rank = rank; m->per = per;
+    const size_t e = c->esz, N = (size_t)c->N, M = (size_t)c->M;
+    void** vecs[] = {&m->p, &m->r, &m->Ap, &m->Kv, &m->b};
+    for (void** q : vecs) CGLB_TRY(dalloc(c, q, N * e));
+    CGLB_TRY(dalloc(c, &m->zseg, (size_t)world * (size_t)(per + 1) * e));
+    CGLB_TRY(dalloc(c, &m->ubuf, (size_t)world * (size_t)per * e));
+    CGLB_TRY(dalloc(c, &m->u, M * e));
+    CGLB_TRY(dalloc(c, &m->aw, M * e));
+    CGLB_TRY(dalloc(c, (void**)&m->sc, 8 * sizeof(double)));
+    CGLB_TRY(dalloc(c, (void**)&m->grad, (size_t)CGLB_GRAD_LEN(c->D, c->M) * sizeof(double)));
+    HIP_CHECK(c, hipMemsetAsync(m->zseg, 0, (size_t)world * (size_t)(per + 1) * e, c->stream));
+    HIP_CHECK(c, hipMemsetAsync(m->ubuf, 0, (size_t)world * (size_t)per * e, c->stream));
+    c->par_world = world;  // cglb_set_parallel: the cyclic deal of the symmetric K_ff work
+    c->par_rank = rank;
+    return CGLB_OK;
+}
+
+int dist_setup(cglb_ctx* c) {
+    CGLB_DISPATCH_T(c->dtype, CGLB_TRY(setup_local_impl<T>(c)));
+    CGLB_TRY(comm_allreduce(c, c->AAt, (int64_t)c->M * c->M));
+    CGLB_DISPATCH_T(c->dtype, CGLB_TRY(setup_finish_impl<T>(c)));
+    return CGLB_OK;
+}
+
+// out = (K_ff + noise I) x on every rank (rank 0's partial carries the noise term)
+int dist_matvec(cglb_ctx* c, const void* x_full, void* out_full) {
+    CGLB_TRY(launch_kff_sym_cyclic(c, x_full, out_full));
+    return comm_allreduce(c, out_full, c->N);
+}
+
+// z = P r (conjugate_gradient.py:73) gathered in segments of per + 1 elements: slice g = rank g's rows and its partial of r^T z
+int dist_precond_gather(cglb_ctx* c, const void* r_full) {
+    cglb_comm_state* m = c->comm;
+    const char* r_loc = (const char*)r_full + (size_t)c->r0 * c->esz;
+    char* slot = (char*)m->zseg + (size_t)m->rank * (size_t)(m->per + 1) * c->esz;
+    if (c->nloc > 0) CGLB_TRY(launch_gemv_u(c, r_loc, m->u));
+    else HIP_CHECK(c, hipMemsetAsync(m->u, 0, (size_t)c->M * c->esz, c->stream));
+    CGLB_TRY(comm_allreduce(c, m->u, c->M));
+    if (c->nloc > 0) {
+        CGLB_TRY(launch_tri_apply(c, m->u, c->w_t));
+        CGLB_TRY(launch_precond_z(c, r_loc, c->w_t, slot, nullptr, slot + (size_t)m->per * c->esz));
+    } else {
+        HIP_CHECK(c, hipMemsetAsync(slot + (size_t)m->per * c->esz, 0, c->esz, c->stream));
+    }
+    return comm_allgather(c, m->zseg, m->per + 1);
+}
+
+// ... then rz_new = r^T z from the gathered partials (rank order) and p = z + p rz_new / rz_old, or p = z (:75)
+int dist_precond_direction(cglb_ctx* c, double* rz_new, const double* rz_old, int restart) {
+    cglb_comm_state* m = c->comm;
+    CGLB_TRY(dist_precond_gather(c, m->r));
+    return launch_update_p_seg(c, m->p, m->zseg, c->N, m->per, m->world, rz_new, rz_old, restart);
+}
+
+// conjugate_gradient.py:41-86 on replicated full vectors - the N-rank twin of pcg_impl (same look-ahead, same stop rule)
+int dist_pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter, int restart_iter, int* steps, double* half_rz) {
+    cglb_comm_state* m = c->comm;
+    double* S = c->scal;
+    const int64_t N = c->N;
+    c->pwh_src = nullptr;
+    double vnorm = 0.0;
+    CGLB_TRY(launch_dot(c, v, v, N, S + S_TMP));
+    CGLB_TRY(read_scalars(c, S + S_TMP, &vnorm, 1));
+    if (vnorm == 0.0) {  // cold start: A v == 0 and r == b exactly (v is replicated: every rank takes the same branch)
+        HIP_CHECK(c, hipMemcpyAsync(m->r, b, (size_t)N * c->esz, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        CGLB_TRY(dist_matvec(c, v, m->Kv));                                                        // :57
+        CGLB_TRY(launch_residual(c, m->r, b, m->Kv, N));                                           // :58
+    }
+    double *s_rz = S + S_RZ, *s_nrz = S + S_NRZ;
+    CGLB_TRY(dist_precond_direction(c, s_rz, s_rz, 1));                                            // :59, :61
+    double rz = 0;
+    CGLB_TRY(read_scalars(c, s_rz, &rz, 1));
+    if (!std::isfinite(rz)) return cglb_fail(c, CGLB_ERR_COMM, "r^T P r is not finite at the start of the solve");  // gathered numbers: same on every rank
+    int i = 0;
+    bool ahead = false;
+    while (0.5 * rz > max_error && i < max_iter) {                                                 // :65
+        if (!ahead) CGLB_TRY(dist_matvec(c, m->p, m->Ap));                                         // :66
+        CGLB_TRY(launch_dot(c, m->p, m->Ap, N, S + S_PAP));                                        // :67
+        const int restart = (restart_iter > 0) && (i % restart_iter == restart_iter - 1);          // :70
+        CGLB_TRY(launch_update_v_r(c, v, m->r, m->p, m->Ap, s_rz, S + S_PAP, !restart, N));        // :68, :72
+        if (restart) {
+            CGLB_TRY(dist_matvec(c, v, m->Kv));
+            CGLB_TRY(launch_residual(c, m->r, b, m->Kv, N));
+        }
+        CGLB_TRY(dist_precond_direction(c, s_nrz, s_rz, restart));                                 // :73, :75
+        std::swap(s_rz, s_nrz);                                                                    // :76
+        HIP_CHECK(c, hipMemcpyAsync(c->host_scal, s_rz, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(c, hipEventRecord(c->scal_event, c->stream));
+        ahead = c->pcg_lookahead && (i + 1 < max_iter) && (0.5 * rz > 4.0 * max_error);
+        if (ahead) CGLB_TRY(dist_matvec(c, m->p, m->Ap));                                          // kernel + all-reduce enqueued before the host waits
+        HIP_CHECK(c, hipEventSynchronize(c->scal_event));
+        rz = c->host_scal[0];  // a function of all-gathered numbers only: every rank reads the same value and leaves the loop together
+        if (!std::isfinite(rz)) return cglb_fail(c, CGLB_ERR_COMM, "r^T P r is not finite after iteration " + std::to_string(i));
+        ++i;
+    }
+    if (steps) *steps = i;
+    if (half_rz) *half_rz = 0.5 * rz;
+    return CGLB_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_pairs_kernel(const T* __restrict__ gat, int64_t pern, int64_t n, T* __restrict__ a, T* __restrict__ b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t g = i / pern, k = i - g * pern;
+    a[i] = gat[g * 2 * pern + k];
+    b[i] = gat[g * 2 * pern + pern + k];
+}
+
 }  // namespace
 
 // =================================================== C ABI ====================================================
@@ -590,11 +794,13 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     if (!c) return CGLB_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
+    comm_free(c);
     void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->Xhsq, c->xah, c->wh, c->pwh, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Mtmp3, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
                     c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : c->k1_events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->eval_events) (void)hipEventDestroy(ev);
     if (c->host_scal) (void)hipHostFree(c->host_scal);
     if (c->scal_event) (void)hipEventDestroy(c->scal_event);
     if (c->blas) (void)rocblas_destroy_handle(c->blas);
@@ -617,10 +823,16 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
         else CGLB_TRY(k1_profile_collect(c));
         c->k1_profile = value != 0;
     }
+    else if (!strcmp(name, "eval_profile")) {  // 1: time the phases of every cglb_objective_and_grad from now on (counters reset), 0: stop
+        if (value) { c->eval_events_used = 0; c->eval_count = 0; for (double& t : c->eval_ms) t = 0.0; }
+        else CGLB_TRY(eval_collect(c));
+        c->eval_profile = value != 0;
+    }
     else if (!strcmp(name, "precision")) {
         if (value != CGLB_PREC_EXACT && value != CGLB_PREC_FAST) return cglb_fail(c, CGLB_ERR_BAD_ARG, "precision must be 0 (exact) or 1 (fast)");
         c->precision = (int)value;
     }
+    else if (!strcmp(name, "drop_weighted_operand")) c->pwh_src = nullptr;  // the vector last written by cglb_vec_update_p_seg is about to change
     else if (!strcmp(name, "chol_mode")) c->chol_mode = (int)value;
     else if (!strcmp(name, "grad_trsm")) c->grad_trsm = (int)value;
     else if (!strcmp(name, "precond_mode")) { c->precond_mode = (int)value; c->have_local = c->have_terms = false; }
@@ -936,7 +1148,10 @@ int cglb_objective_and_grad(cglb_ctx* c, void* v_inout, int run_cg, double max_e
     if (!c || !v_inout || !out4) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
     c->obj_valid = false;
     CGLB_TRY(require_single(c));
+    if (c->eval_profile && c->eval_events_used + 5 > 5 * 512) CGLB_TRY(eval_collect(c));  // bounded pool
+    CGLB_TRY(eval_mark(c));
     CGLB_TRY(cglb_setup(c));                                                        // models.py:155
+    CGLB_TRY(eval_mark(c));
     if (steps) *steps = 0;
     if (half_rz) *half_rz = std::nan("");
     if (run_cg) {                                                                   // models.py:262-278
@@ -944,13 +1159,16 @@ int cglb_objective_and_grad(cglb_ctx* c, void* v_inout, int run_cg, double max_e
         // w_e is reused by phase1, which recomputes it; pcg reads it as b
         CGLB_TRY(pcg_impl(c, c->w_e, v_inout, max_error, max_cg_iter, restart_cg_iter, steps, half_rz));
     }
+    CGLB_TRY(eval_mark(c));
     double* sc = c->scal + S_SC;
     CGLB_TRY(obj_phase1(c, v_inout, c->w_u));
     CGLB_TRY(obj_phase2(c, v_inout, c->w_u, sc, c->w_u));  // aw overwrites u after u has been consumed (stream order)
+    CGLB_TRY(eval_mark(c));
     if (grad) {
         CGLB_DISPATCH_T(c->dtype, CGLB_TRY(obj_phase3_impl<T>(c, v_inout, sc, c->w_u, c->gradbuf)));
         HIP_CHECK(c, hipMemcpyAsync(grad, c->gradbuf, (size_t)CGLB_GRAD_LEN(c->D, c->M) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
+    CGLB_TRY(eval_mark(c));
     CGLB_TRY(obj_finish(c, sc, out4));
     c->obj_valid = true;  // r = e - K v and w = P r of this evaluation stay in the work vectors (cglb_objective_grad_v)
     return CGLB_OK;
@@ -1002,13 +1220,17 @@ int cglb_select_inducing(cglb_ctx* c, const double* lengthscales, double varianc
     return rc;
 }
 
-int cglb_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var) {
-    if (c) c->obj_valid = false;
-    if (!c || !v_full || !xnew || !f_mean || !f_var || n_new < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
-    CGLB_TRY(require_single(c));
-    CGLB_TRY(require_terms(c));
-    if (n_new == 0) return CGLB_OK;
-    HIP_CHECK(c, hipSetDevice(c->device));
+// res = (y - mean) - Kv over the local rows, u_partial = A_loc res  (models.py:318, :335, :340)
+static int predict_u_local(cglb_ctx* c, const void* Kv_local, void* u_partial) {
+    const char* y_loc = (const char*)c->y + (size_t)c->r0 * c->esz;
+    CGLB_TRY(launch_sub_scalar(c, c->w_e, y_loc, c->mean, c->nloc));
+    CGLB_TRY(launch_residual(c, c->w_r, c->w_e, Kv_local));
+    if (c->nloc == 0) { HIP_CHECK(c, hipMemsetAsync(u_partial, 0, (size_t)c->M * c->esz, c->stream)); return CGLB_OK; }
+    return launch_gemv_u(c, c->w_r, u_partial);
+}
+
+// c = LB^-1 u / sigma (:343) into w_u, then for the n_new points of xnew: cg_mean (:334), K_us panel, tmp1, tmp2 (:344-345), mean / var (:347-351)
+static int predict_rows(cglb_ctx* c, const void* v_full, const void* u, const void* xnew, int64_t n_new, void* f_mean, void* f_var) {
     const int M = c->M;
     const int64_t ld = (n_new + 7) & ~(int64_t)7;
     void *xr = nullptr, *xs = nullptr, *xa = nullptr, *t1 = nullptr, *t2 = nullptr;
@@ -1023,10 +1245,7 @@ int cglb_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_ne
         CGLB_TRY(launch_prep_scaled(c, xr, n_new, xs, xa, true));               // hot units for the pair kernel
         CGLB_TRY(launch_cross_matvec(c, xs, xa, n_new, v_full, f_mean));       // cg_mean = ksf @ v   (models.py:334)
         CGLB_TRY(launch_prep_scaled(c, xr, n_new, xs, xa, false));             // plain scaled units for the K_us panel
-        CGLB_TRY(launch_sub_scalar(c, c->w_e, c->y, c->mean, c->nloc));        // err                  (:318)
-        CGLB_TRY(launch_kff_matvec(c, v_full, c->w_Kv, nullptr));
-        CGLB_TRY(launch_residual(c, c->w_r, c->w_e, c->w_Kv));                 // res = err - cov @ v  (:335)
-        CGLB_TRY(launch_gemv_u(c, c->w_r, c->w_u));                            // a_res = A @ res      (:340)
+        if (u != c->w_u) HIP_CHECK(c, hipMemcpyAsync(c->w_u, u, (size_t)M * c->esz, hipMemcpyDeviceToDevice, c->stream));
         CGLB_DISPATCH_T(c->dtype, {
             const T one = 1;
             const T inv_sigma = (T)(1.0 / std::sqrt(c->noise));
@@ -1053,6 +1272,192 @@ int cglb_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_ne
     return rc;
 }
 
+int cglb_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var) {
+    if (c) c->obj_valid = false;
+    if (!c || !v_full || !xnew || !f_mean || !f_var || n_new < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_single(c));
+    CGLB_TRY(require_terms(c));
+    if (n_new == 0) return CGLB_OK;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_TRY(launch_kff_matvec(c, v_full, c->w_Kv, nullptr));               // cov @ v            (:335)
+    CGLB_TRY(predict_u_local(c, c->w_Kv, c->w_u));                          // a_res = A @ res    (:340)
+    return predict_rows(c, v_full, c->w_u, xnew, n_new, f_mean, f_var);
+}
+
+int cglb_shard_predict_u(cglb_ctx* c, const void* Kv_local, void* u_partial) {
+    if (c) c->obj_valid = false;
+    if (!c || (!Kv_local && c->nloc > 0) || !u_partial) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return predict_u_local(c, Kv_local, u_partial);
+}
+
+int cglb_shard_predict_rows(cglb_ctx* c, const void* v_full, const void* u, const void* xnew, int64_t n_new, void* f_mean, void* f_var) {
+    if (c) c->obj_valid = false;
+    if (!c || !v_full || !u || n_new < 0 || (n_new > 0 && (!xnew || !f_mean || !f_var))) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_terms(c));
+    if (n_new == 0) return CGLB_OK;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return predict_rows(c, v_full, u, xnew, n_new, f_mean, f_var);
+}
+
+
+// ---- N ranks inside the library --------------------------------------------------------------------------------------
+int cglb_comm_get_unique_id(void* id_out) {
+    if (!id_out) return CGLB_ERR_BAD_ARG;
+    static_assert(sizeof(ncclUniqueId) == CGLB_COMM_ID_BYTES, "RCCL unique id size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return CGLB_ERR_COMM;
+    std::memcpy(id_out, &id, sizeof(id));
+    return CGLB_OK;
+}
+
+int cglb_comm_init_rccl(cglb_ctx* c, const void* unique_id, int world, int rank) {
+    if (!c || !unique_id) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_TRY(comm_alloc(c, world, rank));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) {
+        comm_free(c);
+        return cglb_fail(c, CGLB_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    }
+    c->comm->kind = 1;
+    c->comm->nccl = (void*)comm;
+    return CGLB_OK;
+}
+
+int cglb_comm_init_callbacks(cglb_ctx* c, int world, int rank, cglb_allreduce_fn allreduce, cglb_allgather_fn allgather, void* user) {
+    if (!c || !allreduce || !allgather) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_TRY(comm_alloc(c, world, rank));
+    c->comm->kind = 2;
+    c->comm->ar = allreduce; c->comm->ag = allgather; c->comm->user = user;
+    return CGLB_OK;
+}
+
+int cglb_comm_destroy(cglb_ctx* c) {
+    if (!c) return CGLB_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    comm_free(c);
+    c->par_world = 1; c->par_rank = 0;
+    return CGLB_OK;
+}
+
+int cglb_dist_setup(cglb_ctx* c) {
+    if (!c) return CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_comm(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return dist_setup(c);
+}
+
+int cglb_dist_matvec(cglb_ctx* c, const void* x_full, void* out_full) {
+    if (!c || !x_full || !out_full) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_comm(c));
+    if (!c->have_hypers) return cglb_fail(c, CGLB_ERR_STATE, "set_hypers must precede matvec");
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return dist_matvec(c, x_full, out_full);
+}
+
+int cglb_dist_precond_apply(cglb_ctx* c, const void* r_full, void* z_full, double* rz) {
+    if (c) c->obj_valid = false;
+    if (!c || !r_full || !z_full) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_comm(c));
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    CGLB_TRY(dist_precond_gather(c, r_full));
+    // p = z through the segmented update (restart form): un-segments the gathered z and sums the partials of r^T z in rank order
+    CGLB_TRY(launch_update_p_seg(c, z_full, c->comm->zseg, c->N, c->comm->per, c->comm->world, c->scal + S_TMP, c->scal + S_TMP, 1));
+    c->pwh_src = nullptr;  // z_full is the caller's vector, not a direction the next mat-vec will consume
+    if (rz) CGLB_TRY(read_scalars(c, c->scal + S_TMP, rz, 1));
+    return CGLB_OK;
+}
+
+int cglb_dist_pcg_solve(cglb_ctx* c, const void* b_full, void* v_full_inout, double max_error, int max_cg_iter, int restart_cg_iter, int* steps,
+                        double* half_rz) {
+    if (c) c->obj_valid = false;
+    if (!c || !b_full || !v_full_inout) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_comm(c));
+    CGLB_TRY(require_terms(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    return dist_pcg_impl(c, b_full, v_full_inout, max_error, max_cg_iter, restart_cg_iter, steps, half_rz);
+}
+
+int cglb_dist_objective_and_grad(cglb_ctx* c, void* v, int run_cg, double max_error, int max_cg_iter, int restart_cg_iter, double* out4,
+                                 double* grad, int* steps, double* half_rz) {
+    if (!c || !v || !out4) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "NULL argument") : CGLB_ERR_BAD_ARG;
+    c->obj_valid = false;
+    CGLB_TRY(require_comm(c));
+    HIP_CHECK(c, hipSetDevice(c->device));
+    cglb_comm_state* m = c->comm;
+    CGLB_TRY(dist_setup(c));                                                        // models.py:155
+    if (steps) *steps = 0;
+    if (half_rz) *half_rz = std::nan("");
+    if (run_cg) {                                                                   // models.py:262-278
+        CGLB_TRY(launch_sub_scalar(c, m->b, c->y, c->mean, c->N));
+        CGLB_TRY(dist_pcg_impl(c, m->b, v, max_error, max_cg_iter, restart_cg_iter, steps, half_rz));
+    }
+    CGLB_TRY(dist_matvec(c, v, m->Kv));                                             // models.py:280
+    // phase 1 with K v given: r = e - K v on the local rows, u_partial = A_loc r
+    const char* y_loc = (const char*)c->y + (size_t)c->r0 * c->esz;
+    CGLB_TRY(launch_sub_scalar(c, c->w_e, y_loc, c->mean, c->nloc));
+    HIP_CHECK(c, hipMemcpyAsync(c->w_Kv, (const char*)m->Kv + (size_t)c->r0 * c->esz, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
+    CGLB_TRY(launch_residual(c, c->w_r, c->w_e, c->w_Kv));
+    if (c->nloc > 0) CGLB_TRY(launch_gemv_u(c, c->w_r, m->u));
+    else HIP_CHECK(c, hipMemsetAsync(m->u, 0, (size_t)c->M * c->esz, c->stream));
+    CGLB_TRY(comm_allreduce(c, m->u, c->M));
+    CGLB_TRY(obj_phase2(c, v, m->u, m->sc, m->aw));
+    CGLB_TRY(comm_allreduce(c, m->sc, 8, true));
+    if (grad) {
+        CGLB_TRY(comm_allreduce(c, m->aw, c->M));
+        // u = w + v/2 on the local rows, gathered: the cyclic share of the N^2 gradient form needs it in full
+        char* u_loc = (char*)m->ubuf + (size_t)m->rank * (size_t)m->per * c->esz;
+        HIP_CHECK(c, hipMemcpyAsync(u_loc, c->w_z, (size_t)c->nloc * c->esz, hipMemcpyDeviceToDevice, c->stream));
+        CGLB_TRY(launch_axpy(c, u_loc, 0.5, (const char*)v + (size_t)c->r0 * c->esz, c->nloc));
+        CGLB_TRY(comm_allgather(c, m->ubuf, m->per));
+        CGLB_DISPATCH_T(c->dtype, CGLB_TRY(obj_phase3_impl<T>(c, v, m->sc, m->aw, m->grad, m->ubuf)));
+        CGLB_TRY(comm_allreduce(c, m->grad, (int64_t)CGLB_GRAD_LEN(c->D, c->M), true));
+        HIP_CHECK(c, hipMemcpyAsync(grad, m->grad, (size_t)CGLB_GRAD_LEN(c->D, c->M) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    return obj_finish(c, m->sc, out4);
+}
+
+int cglb_dist_predict(cglb_ctx* c, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var) {
+    if (c) c->obj_valid = false;
+    if (!c || !v_full || !xnew || !f_mean || !f_var || n_new < 0) return c ? cglb_fail(c, CGLB_ERR_BAD_ARG, "bad argument") : CGLB_ERR_BAD_ARG;
+    CGLB_TRY(require_comm(c));
+    CGLB_TRY(require_terms(c));
+    if (n_new == 0) return CGLB_OK;
+    HIP_CHECK(c, hipSetDevice(c->device));
+    cglb_comm_state* m = c->comm;
+    CGLB_TRY(dist_matvec(c, v_full, m->Kv));                                                            // cov @ v  (models.py:335)
+    CGLB_TRY(predict_u_local(c, (const char*)m->Kv + (size_t)c->r0 * c->esz, m->u));                    // a_res partial (:340)
+    CGLB_TRY(comm_allreduce(c, m->u, c->M));
+    // the new points are dealt to the ranks in contiguous slices of pern rows; slice g lands at [g * 2 pern, ...): mean then variance
+    const int64_t pern = (n_new + m->world - 1) / m->world;
+    const int64_t a = std::min<int64_t>((int64_t)m->rank * pern, n_new), b = std::min<int64_t>((int64_t)(m->rank + 1) * pern, n_new);
+    const size_t need = (size_t)m->world * 2 * (size_t)pern * c->esz;
+    if (need > m->gat_cap) {
+        if (m->gat) HIP_CHECK(c, hipFree(m->gat));
+        m->gat = nullptr; m->gat_cap = 0;
+        HIP_CHECK(c, hipMalloc(&m->gat, need));
+        m->gat_cap = need;
+    }
+    char* mine = (char*)m->gat + (size_t)m->rank * 2 * (size_t)pern * c->esz;
+    if (b > a) {
+        // xnew may be host or device memory: element offsets are the same either way
+        CGLB_TRY(predict_rows(c, v_full, m->u, (const char*)xnew + (size_t)a * c->D * c->esz, b - a, mine, mine + (size_t)pern * c->esz));
+    }
+    CGLB_TRY(comm_allgather(c, m->gat, 2 * pern));
+    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((unpack_pairs_kernel<T>), dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, c->stream,
+                                                 (const T*)m->gat, pern, n_new, (T*)f_mean, (T*)f_var));
+    CGLB_LAUNCH_CHECK(c);
+    HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return CGLB_OK;
+}
+
 int cglb_get_matrix(cglb_ctx* c, int which, void* dst) {
     if (!c || !dst) return CGLB_ERR_BAD_ARG;
     CGLB_TRY(require_terms(c));
@@ -1077,8 +1482,17 @@ int cglb_get_stat(cglb_ctx* c, const char* name, double* value) {
         *value = !strcmp(name, "k1_ms_total") ? c->k1_ms_total : (double)c->k1_launches;
         return CGLB_OK;
     }
+    {
+        static const char* names[] = {"eval_setup_ms", "eval_pcg_ms", "eval_final_ms", "eval_grad_ms"};
+        for (int k = 0; k < 4; ++k)
+            if (!strcmp(name, names[k])) { CGLB_TRY(eval_collect(c)); *value = c->eval_ms[k]; return CGLB_OK; }
+        if (!strcmp(name, "eval_count")) { CGLB_TRY(eval_collect(c)); *value = (double)c->eval_count; return CGLB_OK; }
+    }
     if (!strcmp(name, "k1_pairs_per_launch")) { *value = c->sym_pairs; return CGLB_OK; }  // of the most recent symmetric launch geometry
     if (!strcmp(name, "kpart_bytes")) { *value = (double)c->kpart_cap; return CGLB_OK; }     // partial-sum slabs of the mat-vec
+    if (!strcmp(name, "comm_allreduce_calls")) { *value = c->comm ? (double)c->comm->n_allreduce : 0.0; return CGLB_OK; }
+    if (!strcmp(name, "comm_allgather_calls")) { *value = c->comm ? (double)c->comm->n_allgather : 0.0; return CGLB_OK; }
+    if (!strcmp(name, "L_diag_ratio")) { *value = c->L_diag_ratio; return CGLB_OK; }         // of the last cglb_setup (chooses the gradient algebra)
     return cglb_fail(c, CGLB_ERR_BAD_ARG, std::string("unknown statistic ") + name);
 }
 

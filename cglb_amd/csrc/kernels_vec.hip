@@ -481,6 +481,34 @@ int launch_sum_log_diag(cglb_ctx* c, const void* Mc, double* slot) {
     return CGLB_OK;
 }
 
+// slot[0] = min, slot[1] = max of the diagonal of a column-major M x M matrix (the spread of diag(L) is a cheap proxy of cond(L))
+template <typename T>
+__global__ __launch_bounds__(256) void diag_minmax_kernel(const T* __restrict__ Mc, int M, double* __restrict__ slot) {
+    __shared__ double smin[256], smax[256];
+    double lo = 1.0e300, hi = -1.0e300;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        const double d = (double)Mc[(int64_t)i * M + i];
+        lo = fmin(lo, d);
+        hi = fmax(hi, d);
+    }
+    smin[threadIdx.x] = lo;
+    smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + s]);
+            smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { slot[0] = smin[0]; slot[1] = smax[0]; }
+}
+int launch_diag_minmax(cglb_ctx* c, const void* Mc, double* slot) {
+    CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((diag_minmax_kernel<T>), dim3(1), dim3(256), 0, c->stream, (const T*)Mc, c->M, slot));
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void symmetrize_lower_kernel(T* __restrict__ Mc, int M) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -271,6 +271,12 @@ class SymLocalOps(LocalOps):
     def obj_phase1_kv(self, Kv_local, u_out): raise NotImplementedError
     def obj_w(self, w_local_out): raise NotImplementedError
     def obj_phase3_cyclic(self, v_full, u_full, sc, aw, grad_out): raise NotImplementedError
+    # hyper-parameter update and the prediction pieces (PredictCG, models.py:307-354) - needed behind the backend API
+    def set_hypers(self, lengthscales, variance, noise, mean, Z, jitter): raise NotImplementedError
+    def y_full(self) -> torch.Tensor: raise NotImplementedError
+    def drop_weighted_operand(self): pass   # HIP: the vector vec_update_p_seg wrote is handed out and may change before the next mat-vec
+    def predict_u(self, Kv_local, u_out): raise NotImplementedError
+    def predict_rows(self, v_full, u, xnew) -> Tuple[torch.Tensor, torch.Tensor]: raise NotImplementedError
 
 
 class HipSymLocalOps(HipLocalOps, SymLocalOps):
@@ -291,6 +297,17 @@ class HipSymLocalOps(HipLocalOps, SymLocalOps):
     def obj_phase1_kv(self, Kv_local, u_out): self._ck(self.lib.cglb_shard_obj_phase1_kv(self.h, self._p(Kv_local), self._p(u_out)))
     def obj_w(self, w_local_out): self._ck(self.lib.cglb_shard_obj_w(self.h, self._p(w_local_out)))
     def obj_phase3_cyclic(self, v_full, u_full, sc, aw, grad_out): self._ck(self.lib.cglb_shard_obj_phase3_cyclic(self.h, self._p(v_full), self._p(u_full), self._p(sc), self._p(aw), self._p(grad_out)))
+    def set_hypers(self, lengthscales, variance, noise, mean, Z, jitter): self.ctx.set_hypers(lengthscales, variance, noise, mean, Z, jitter)
+    def y_full(self): return self.ctx.y
+    def drop_weighted_operand(self): self.ctx.set_option("drop_weighted_operand", 1)
+    def predict_u(self, Kv_local, u_out): self._ck(self.lib.cglb_shard_predict_u(self.h, self._p(Kv_local), self._p(u_out)))
+
+    def predict_rows(self, v_full, u, xnew):
+        xn = torch.as_tensor(xnew, dtype=self.dtype).reshape(-1, self.D).contiguous().to(self.device)
+        n = int(xn.shape[0])
+        mean, var = torch.empty(max(n, 1), dtype=self.dtype, device=self.device), torch.empty(max(n, 1), dtype=self.dtype, device=self.device)
+        self._ck(self.lib.cglb_shard_predict_rows(self.h, self._p(v_full), self._p(u), self._p(xn) if n else None, n, self._p(mean), self._p(var)))
+        return mean[:n], var[:n]
 
 
 class SymShardedCGLB:
@@ -387,10 +404,26 @@ class SymShardedCGLB:
             # the value is a function of all-gathered numbers only: every rank sees the same one and leaves the loop here together
             raise FloatingPointError(f"r^T P r is not finite {where}: {rz}")
 
-    def pcg(self, max_error=1.0, max_cg_iter=100, restart_cg_iter=40) -> Tuple[int, float]:
-        """conjugate_gradient.py:41-86 on replicated full vectors; v is updated in place."""
+    def precond_apply(self, r_full) -> Tuple[torch.Tensor, float]:
+        """z = (Q_ff + noise I)^-1 r on full replicated vectors (the preconditioner seam, conjugate_gradient.py:95-113)."""
+        saved = self.r
+        self.r = r_full
+        z = torch.zeros_like(self.p)
+        p_saved, self.p = self.p, z
+        try:
+            self._precond_and_direction(self.scratch, self.scratch, True)   # p = z, scratch = r^T z from the gathered partials
+            self.ops.drop_weighted_operand()
+        finally:
+            self.r, self.p = saved, p_saved
+        return z, float(self.scratch.item())
+
+    def pcg(self, max_error=1.0, max_cg_iter=100, restart_cg_iter=40, b=None) -> Tuple[int, float]:
+        """conjugate_gradient.py:41-86 on replicated full vectors; v is updated in place.  b: right-hand side (default y - mean)."""
         ops, N = self.ops, self.N
-        ops.rhs_full(self.b)
+        if b is None:
+            ops.rhs_full(self.b)
+        else:
+            self.b.copy_(b)
         ops.vec_dot(N, self.v, self.v, self.scratch)
         if float(self.scratch.item()) == 0.0:
             # cold start (models.py:59-68): A v == 0 and r == b exactly, so the mat-vec and its all-reduce are skipped
@@ -450,3 +483,100 @@ class SymShardedCGLB:
             grad = self.grad.detach().cpu().numpy().copy()
         bound, lower, upper, logdet = ops.obj_finish(self.sc)
         return ShardedResult(bound, lower, upper, logdet, steps, half, grad)
+
+    def predict(self, xnew) -> Tuple[torch.Tensor, torch.Tensor]:
+        """PredictCG.forward after the solve (models.py:334-352) at self.v: K v by the cyclic mat-vec, a_res = A res all-reduced (M),
+        then the new points are dealt to the ranks in contiguous slices (each rank evaluates k(x*, X) v over ALL columns and the SGPR
+        terms for its slice) and the per-slice (mean, variance) pairs are all-gathered.  Returns full-length tensors on every rank."""
+        ops, comm, G = self.ops, self.comm, self.comm.world
+        xn = torch.as_tensor(xnew, dtype=ops.dtype).reshape(-1, self.D)
+        n_new = int(xn.shape[0])
+        self.matvec(self.v, self.Kv)                                          # :335
+        ops.predict_u(self.Kv[self.r0:self.r1], self.u)                       # :340
+        comm.allreduce(self.u)
+        pern = (n_new + G - 1) // G
+        a, b = min(comm.rank * pern, n_new), min((comm.rank + 1) * pern, n_new)
+        gat = torch.zeros(max(G * 2 * pern, 1), dtype=ops.dtype, device=ops.device)
+        if b > a:
+            mean, var = ops.predict_rows(self.v, self.u, xn[a:b])
+            base = comm.rank * 2 * pern
+            gat[base: base + (b - a)].copy_(mean)
+            gat[base + pern: base + pern + (b - a)].copy_(var)
+        if pern > 0:
+            comm.allgather_inplace(gat, 2 * pern)
+        seg = gat[: G * 2 * pern].reshape(G, 2, pern) if pern > 0 else gat.reshape(0, 2, 0)
+        return seg[:, 0, :].reshape(-1)[:n_new].clone(), seg[:, 1, :].reshape(-1)[:n_new].clone()
+
+
+class PyDistContext:
+    """The `HipContext` surface over the HOST-DRIVEN twin of the N-rank path (SymShardedCGLB + any SymLocalOps): what the backend's
+    model classes talk to when the collectives are issued from Python.  With `HipSymLocalOps` it is the step-by-step form of
+    `dist_context.DistHipContext` (same kernels, same collectives, one C call per phase); with CPU local ops it lets the backend API
+    (LowerBoundCG, optimize, PredictCG, metrics_fn) run at world size > 1 over gloo without a GPU in the tests."""
+
+    def __init__(self, ops: SymLocalOps, comm: Optional[Comm] = None):
+        self.ops = ops
+        self.drv = SymShardedCGLB(ops, comm)
+        self.comm = self.drv.comm
+        self.world, self.rank = self.comm.world, self.comm.rank
+        self.N, self.M, self.D = ops.N, ops.M, ops.D
+        self.device, self.dtype = ops.device, ops.dtype
+        self.r0, self.r1 = 0, ops.N       # vectors handed in / out are full length
+        self.y = ops.y_full()
+        self.noise = None
+
+    def close(self):
+        ctx = getattr(self.ops, "ctx", None)
+        if ctx is not None:
+            ctx.close()
+
+    def _dev(self, t, n=None):
+        t = torch.as_tensor(t, dtype=self.dtype, device=self.device).reshape(-1).contiguous()
+        if n is not None and t.numel() != n:
+            raise ValueError(f"expected a vector of length {n}, got {t.numel()}")
+        return t
+
+    def empty(self, n):
+        return torch.empty(n, dtype=self.dtype, device=self.device)
+
+    def set_hypers(self, lengthscales, variance, noise, mean, Z, jitter=1e-6):
+        self.ops.set_hypers(np.asarray(lengthscales, dtype=np.float64).reshape(-1), float(variance), float(noise), float(mean), Z, float(jitter))
+        self.noise = float(noise)
+
+    def setup(self):
+        self.drv.setup()
+
+    def matvec(self, p_full, out=None):
+        out = self.empty(self.N) if out is None else out
+        self.drv.matvec(self._dev(p_full, self.N), out)
+        return out
+
+    def precond(self, r):
+        return self.drv.precond_apply(self._dev(r, self.N))
+
+    def pcg(self, b, v0, max_error=1.0, max_cg_iter=100, restart_cg_iter=40):
+        self.drv.v.copy_(self._dev(v0, self.N))      # the driver's own v: the caller's tensor is not mutated (conjugate_gradient.py:55)
+        steps, half = self.drv.pcg(max_error, max_cg_iter, restart_cg_iter, b=self._dev(b, self.N))
+        return self.drv.v.clone(), steps, half
+
+    def objective_and_grad(self, v_inout, run_cg=True, max_error=1.0, max_cg_iter=100, restart_cg_iter=40, with_grad=True):
+        from .hip_context import ObjectiveResult
+        if v_inout.numel() != self.N:
+            raise ValueError("v_inout must be a vector of length N")
+        self.drv.v.copy_(v_inout.reshape(-1))
+        res = self.drv.objective_and_grad(run_cg, max_error, max_cg_iter, restart_cg_iter, with_grad)
+        if run_cg:
+            v_inout.reshape(-1).copy_(self.drv.v)
+        grad = None
+        if res.grad is not None:
+            D, M, g = self.D, self.M, res.grad
+            grad = {"lengthscales": g[:D].copy(), "variance": float(g[D]), "noise": float(g[D + 1]), "mean": float(g[D + 2]),
+                    "Z": g[D + 3:].reshape(M, D).copy()}
+        return ObjectiveResult(res.bound, res.lower, res.upper, res.logdet, res.steps, res.residual_error, grad)
+
+    def objective_grad_v(self):
+        raise NotImplementedError("joint optimisation of v (the TF twin's opt-in) is not available on more than one rank")
+
+    def predict(self, v_full, xnew):
+        self.drv.v.copy_(self._dev(v_full, self.N))
+        return self.drv.predict(xnew)

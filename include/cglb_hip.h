@@ -15,8 +15,10 @@
  *   - Every function returns 0 (CGLB_OK) or an error code; cglb_last_error() gives the text.
  *   - One ctx = one GPU = one row shard [row_begin,row_end) of the N training rows.  With a single
  *     shard (row_begin=0,row_end=N) the fused calls (cglb_pcg_solve, cglb_objective_and_grad) do the
- *     whole job.  With several shards (one process per GPU) the host drives the cglb_shard_* phases
- *     and performs the collectives (RCCL through torch.distributed) between them.
+ *     whole job.  With several shards (one process per GPU) either the library runs the loops itself and
+ *     issues the collectives on its stream (cglb_comm_init_* + cglb_dist_*: RCCL, or callbacks), or the
+ *     host drives the cglb_shard_* / cglb_vec_* phases and performs the collectives between them
+ *     (cglb_amd/distributed.py: the same scheme step by step, testable over gloo with CPU local ops).
  *   - Calls on one ctx are serialised by the caller (the reference is single-threaded Python with a
  *     blocking sync per CG iteration, conjugate_gradient.py:80-81).  Work is enqueued on the HIP stream
  *     given at creation; functions that return host scalars synchronise that stream, the others do not.
@@ -32,7 +34,7 @@ extern "C" {
 
 typedef struct cglb_ctx cglb_ctx;
 
-enum { CGLB_OK = 0, CGLB_ERR_BAD_ARG = 1, CGLB_ERR_NOT_PD = 2, CGLB_ERR_HIP = 3, CGLB_ERR_BLAS = 4, CGLB_ERR_STATE = 5 };
+enum { CGLB_OK = 0, CGLB_ERR_BAD_ARG = 1, CGLB_ERR_NOT_PD = 2, CGLB_ERR_HIP = 3, CGLB_ERR_BLAS = 4, CGLB_ERR_STATE = 5, CGLB_ERR_COMM = 6 };
 enum { CGLB_RBF = 0, CGLB_MATERN32 = 1 };      /* config.py:72-81 SquaredExponentialConfig / Matern32Config */
 enum { CGLB_F64 = 0, CGLB_F32 = 1 };           /* pytorch/interface.py:94-104 set_default_float */
 
@@ -170,6 +172,49 @@ int cglb_shard_obj_phase3_cyclic(cglb_ctx* ctx, const void* v_full, const void* 
 /* ---- prediction seam: PredictCG.forward, models.py:307-354 (needs common terms + a solved v) ------ */
 /* f_mean, f_var: dev [n_new].  v_full: dev [n] solution at tolerance 1e-3 (models.py:291). single shard. */
 int cglb_predict(cglb_ctx* ctx, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var);
+/* sharded pieces of the same computation (host or library all-reduces between them):
+ *   _u:    res = (y - mean) - Kv over the local rows (models.py:335), u_partial = A_loc res (:340)             -> all-reduce u[m]
+ *   _rows: c = LB^-1 u / sigma (:343) and, for the new points handed to THIS rank (any subset of the rows of xnew - the driver deals
+ *          contiguous slices to the ranks and all-gathers the results), cg_mean = k(xnew, X) v over ALL n_total columns (:334),
+ *          tmp1, tmp2 (:344-345), f_mean, f_var (:347-351). */
+int cglb_shard_predict_u(cglb_ctx* ctx, const void* Kv_local /* dev [n_local]: (K_ff + noise I) v on the local rows */, void* u_partial /* dev [m] */);
+int cglb_shard_predict_rows(cglb_ctx* ctx, const void* v_full, const void* u /* dev [m], reduced */, const void* xnew, int64_t n_new, void* f_mean,
+                            void* f_var);
+
+/* ---- N ranks inside the library ------------------------------------------------------------------------------------
+ * The cyclic-symmetric scheme above with its collectives issued by the library itself on the context stream, so that a PCG
+ * iteration at world N is enqueued like the single-GPU one: no host work between the kernels of an iteration except the one
+ * read-back of the stop statistic (conjugate_gradient.py:65,80-81), which the look-ahead hides.  One process per GPU; every
+ * rank makes the same calls with the same arguments.  The context must own the rows of the contiguous partition
+ * [rank * per, min((rank + 1) * per, n_total)), per = ceil(n_total / world), and use the stored-panel preconditioner.
+ *   cglb_comm_get_unique_id: rank 0 obtains the RCCL id (CGLB_COMM_ID_BYTES bytes) and hands it to the other ranks through the
+ *     launcher's store (torch.distributed's TCPStore in cglb_amd/dist_context.py); cglb_comm_init_rccl is collective.
+ *   cglb_comm_init_callbacks: the same loops over collectives the HOST provides (buffers are device pointers of the context's
+ *     device; in place; the callback must order itself after the work already enqueued on `stream` and leave the result visible
+ *     to work enqueued on `stream` afterwards; return 0 on success).  Used to run the library's N-rank loops over gloo in the
+ *     tests (several ranks sharing one GPU, which RCCL refuses) and available for any other fabric. */
+#define CGLB_COMM_ID_BYTES 128
+typedef int (*cglb_allreduce_fn)(void* user, void* buf, int64_t count, int dtype /* CGLB_F64 | CGLB_F32 */, void* stream);
+/* in place: rank g's contribution sits at element g * count_per_rank of buf (world * count_per_rank elements) */
+typedef int (*cglb_allgather_fn)(void* user, void* buf, int64_t count_per_rank, int dtype, void* stream);
+int cglb_comm_get_unique_id(void* id_out /* host, CGLB_COMM_ID_BYTES */);
+int cglb_comm_init_rccl(cglb_ctx* ctx, const void* unique_id /* host, CGLB_COMM_ID_BYTES */, int world, int rank);
+int cglb_comm_init_callbacks(cglb_ctx* ctx, int world, int rank, cglb_allreduce_fn allreduce, cglb_allgather_fn allgather, void* user);
+int cglb_comm_destroy(cglb_ctx* ctx);
+/* common terms with B = I + sum_g A_g A_g^T (one all-reduce of m x m) */
+int cglb_dist_setup(cglb_ctx* ctx);
+/* out = (K_ff + noise I) x, full length on every rank (this rank's cyclic share + all-reduce). x_full, out_full: dev [n_total] */
+int cglb_dist_matvec(cglb_ctx* ctx, const void* x_full, void* out_full);
+/* z = (Q_ff + noise I)^-1 r on full replicated vectors; rz: host, may be NULL */
+int cglb_dist_precond_apply(cglb_ctx* ctx, const void* r_full, void* z_full, double* rz);
+/* cglb_pcg_solve / cglb_objective_and_grad / cglb_predict on N ranks: vectors are full length and replicated (b_full, v_full_inout,
+ * f_mean, f_var identical on every rank afterwards); host outputs are identical on every rank.  The stop test is taken on
+ * all-gathered per-rank partials of r^T P r, so every rank leaves the loop at the same step by construction. */
+int cglb_dist_pcg_solve(cglb_ctx* ctx, const void* b_full, void* v_full_inout, double max_error, int max_cg_iter, int restart_cg_iter,
+                        int* steps, double* half_rz);
+int cglb_dist_objective_and_grad(cglb_ctx* ctx, void* v_full_inout, int run_cg, double max_error, int max_cg_iter, int restart_cg_iter,
+                                 double* out4, double* grad, int* steps, double* half_rz);
+int cglb_dist_predict(cglb_ctx* ctx, const void* v_full, const void* xnew, int64_t n_new, void* f_mean, void* f_var);
 
 /* ---- inducing-point initialisation: InducingVariableConfig.init, config.py:55-65 ------------------------
  * The reference calls robustgp.ConditionalVariance(sample=False) (third-party): greedy maximisation of the conditional
@@ -193,10 +238,18 @@ int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
  * kernel (in mat-vecs, solves and evaluations alike) is bracketed by HIP events on the context stream; "k1_ms_total" and
  * "k1_launches" return the accumulated device time and launch count since then (the call synchronises with the pending launches).
  * "k1_pairs_per_launch": kernel pairs one launch of that kernel evaluates with the current geometry (~N(N+256)/2 on one GPU: the
- * symmetric form visits each unordered pair once) - the unit count of the roofline; "kpart_bytes": size of the partial-sum slabs. */
+ * symmetric form visits each unordered pair once) - the unit count of the roofline; "kpart_bytes": size of the partial-sum slabs;
+ * after cglb_set_option(ctx, "eval_profile", 1): "eval_setup_ms" | "eval_pcg_ms" | "eval_final_ms" | "eval_grad_ms" = device time (HIP events on
+ * the context stream) accumulated over the phases of every cglb_objective_and_grad since - common terms | PCG | final mat-vec, preconditioner
+ * and bound scalars | gradient - and "eval_count" = the number of evaluations;
+ * "comm_allreduce_calls" | "comm_allgather_calls": collectives issued by the library since cglb_comm_init_*;
+ * "L_diag_ratio": max/min of diag(chol(K_uu + jitter I)) of the last cglb_setup (option "grad_trsm" = 2 compares it with 100). */
 int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
-/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "grad_trsm" | "pcg_lookahead" | "sym_order" | "aat_block" | "grad_gram" | "k1_profile" |
+/* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" | "sym_order" | "aat_block" | "grad_gram" | "k1_profile" |
+ * "grad_trsm" (gradient algebra against L = chol(K_uu): 0 products with the explicit inverse, 1 backward-stable triangular solves, 2 = default:
+ *  the solves whenever diag(L) spreads over more than two decades, i.e. K_uu is ill conditioned) |
  * "precision" (1, default: kernel values to <= 1e-13 relative - degree-3 table polynomial, one-step square root; 0: ~3e-16) ...;
+ * "drop_weighted_operand" (any value: forget the pre-weighted copy cglb_vec_update_p_seg made of its p - for callers that modify p before the next mat-vec);
  * returns CGLB_ERR_BAD_ARG if unknown. */
 int cglb_set_option(cglb_ctx* ctx, const char* name, int64_t value);
 

@@ -20,6 +20,16 @@ class OracleLocalOps(LocalOps):
         self.Kloc = orc.kernel_matrix(kind, X[r0:r1], X, hyp.lengthscales, hyp.variance)  # K_ff[I_g, :]
         self._aat = torch.zeros(self.M * self.M, dtype=torch.float64)
 
+    def set_hypers(self, lengthscales, variance, noise, mean, Z, jitter):
+        Z = np.asarray(Z.detach().cpu().numpy() if isinstance(Z, torch.Tensor) else Z, dtype=np.float64).reshape(self.M, self.D)
+        self.hyp = orc.Hypers(np.asarray(lengthscales, dtype=np.float64).reshape(-1).copy(), float(variance), float(noise), float(mean), Z.copy(), float(jitter))
+        self.Kloc = orc.kernel_matrix(self.kind, self.X[self.r0:self.r1], self.X, self.hyp.lengthscales, self.hyp.variance)
+        if hasattr(self, "Kfull"):
+            self.Kfull = orc.kernel_matrix(self.kind, self.X, self.X, self.hyp.lengthscales, self.hyp.variance)
+
+    def y_full(self):
+        return torch.from_numpy(np.asarray(self.y, dtype=np.float64).copy())
+
     # common terms
     def setup_local(self):
         h = self.hyp
@@ -230,3 +240,22 @@ class OracleSymLocalOps(OracleLocalOps, SymLocalOps):
                 dl = Xs[a:b, d][:, None] - Xs[a:, d][None, :]
                 g[d] += (W * dl * dl).sum() / ls[d]
         grad.copy_(torch.from_numpy(g))
+
+    # prediction pieces (PredictCG.forward, models.py:334-352)
+    def predict_u(self, Kv_local, u):
+        res = (self.y[self.r0:self.r1] - self.hyp.mean) - Kv_local.numpy()
+        u.copy_(torch.from_numpy(self.A @ res))
+
+    def predict_rows(self, v_full, u, xnew):
+        h = self.hyp
+        xn = np.asarray(xnew.numpy() if isinstance(xnew, torch.Tensor) else xnew, dtype=np.float64).reshape(-1, self.D)
+        if xn.shape[0] == 0:
+            return torch.zeros(0, dtype=torch.float64), torch.zeros(0, dtype=torch.float64)
+        cg_mean = orc.kernel_matrix(self.kind, xn, self.X, h.lengthscales, h.variance) @ v_full.numpy()      # :334
+        kus = orc.kernel_matrix(self.kind, h.Z, xn, h.lengthscales, h.variance)                              # :337
+        c = sla.solve_triangular(self.LB, u.numpy(), lower=True) / math.sqrt(h.noise)                        # :343
+        tmp1 = sla.solve_triangular(self.L, kus, lower=True)                                                 # :344
+        tmp2 = sla.solve_triangular(self.LB, tmp1, lower=True)                                               # :345
+        mean = tmp2.T @ c + cg_mean + h.mean                                                                 # :347-348
+        var = orc.kernel_diag(self.kind, xn, h.variance) + (tmp2 ** 2).sum(0) - (tmp1 ** 2).sum(0)           # :350-351
+        return torch.from_numpy(mean), torch.from_numpy(var)

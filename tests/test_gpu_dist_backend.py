@@ -1,0 +1,295 @@
+"""The N-rank path inside libcglb_hip.so (cglb_comm_init_* / cglb_dist_*, `dist_context.DistHipContext`) and through the backend API.
+
+A one-GPU box cannot run RCCL with more than one rank ("Duplicate GPU detected"), so:
+  * RCCL itself is exercised at world size 1 (every collective of the loop is issued through ncclAllReduce / ncclAllGather on the
+    context stream) and compared with the fused single-GPU path;
+  * the SAME library loops run at world size 2 and 3 with the ranks sharing cuda:0 and the collectives provided by callbacks into
+    torch.distributed over gloo (`cglb_comm_init_callbacks`), compared with the fused path, with the host-driven twin
+    (`distributed.PyDistContext` over the HIP local ops: bit-identical) and with the oracle;
+  * the backend API (LowerBoundCG / optimize / PredictCG / metrics_fn, cli under torch.distributed.run) runs on 2 ranks the same way.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN_DIR, ROOT, golden_hypers, load_golden
+from oracle import cglb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawn(target, world, args, n_results, timeout=600):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=timeout) for _ in range(n_results)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return sorted(out, key=lambda t: t[0])
+
+
+def _init(rank, world, port, backend="gloo"):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist
+
+
+# ---------------------------------------------------------------------------------------------------------------- world 1 over RCCL
+def _rccl_world1_worker(rank, world, port, name, q):
+    dist = _init(rank, world, port, "nccl")
+    try:
+        from cglb_amd.dist_context import DistHipContext
+        from cglb_amd.hip_context import HipContext
+        g = load_golden(name)
+        hyp = golden_hypers(g)
+        args = (float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+        M = hyp.Z.shape[0]
+        fused = HipContext(g["X"], g["y"], M, int(g["kind"]))
+        fused.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, hyp.Z, hyp.jitter)
+        v1 = torch.from_numpy(g["v0"]).to(fused.device).clone()
+        r1 = fused.objective_and_grad(v1, True, *args)
+        ctx = DistHipContext(g["X"], g["y"], M, int(g["kind"]), collectives="rccl")
+        ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, hyp.Z, hyp.jitter)
+        v2 = torch.from_numpy(g["v0"]).to(ctx.device).clone()
+        r2 = ctx.objective_and_grad(v2, True, *args)
+        n_ar, n_ag = ctx.get_stat("comm_allreduce_calls"), ctx.get_stat("comm_allgather_calls")
+        xnew = np.random.default_rng(1).standard_normal((50, g["X"].shape[1]))
+        fused.setup(); ctx.setup()
+        p1 = fused.predict(v1, xnew)
+        p2 = ctx.predict(v2, xnew)
+        q.put((rank, r1.steps, r2.steps, r1.bound, r2.bound, v1.cpu().numpy(), v2.cpu().numpy(), r1.grad, r2.grad, n_ar, n_ag,
+               [t.cpu().numpy() for t in p1], [t.cpu().numpy() for t in p2]))
+        ctx.close(); fused.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["rbf_d8_trained", "m32_d8_restart", "rbf_d8_warm"])
+def test_library_loop_over_rccl_world1_equals_fused_path(name):
+    (_, s1, s2, b1, b2, v1, v2, g1, g2, n_ar, n_ag, p1, p2), = _spawn(_rccl_world1_worker, 1, (name,), 1)
+    # the two loops differ in summation order only (p^T A p fused into the slab combine vs a separate dot over the all-reduced product):
+    # identical step counts up to the first restart, +-1 beyond (a > 40-step solve at tolerance 1e-6 amplifies last-bit differences,
+    # DESIGN.md section 2 "parity policy"); with equal step counts everything agrees to round-off
+    assert abs(s1 - s2) <= (0 if s1 <= 40 else 1)
+    if s1 == s2:
+        assert b2 == pytest.approx(b1, rel=1e-11)
+        np.testing.assert_allclose(v2, v1, rtol=0, atol=1e-10 * np.abs(v1).max())
+        for k in ("lengthscales", "Z"):
+            np.testing.assert_allclose(g2[k], g1[k], rtol=1e-8, atol=1e-10 * np.abs(g1[k]).max())
+        for k in ("variance", "noise", "mean"):
+            assert g2[k] == pytest.approx(g1[k], rel=1e-8, abs=1e-9 * abs(b1))
+    else:
+        assert b2 == pytest.approx(b1, rel=1e-6)
+    # every collective went through RCCL: per evaluation 1 (AA^T) + per mat-vec 1 + per preconditioner apply 1 all-reduce and 1 all-gather
+    # + u, sc, aw, grad (4) all-reduces and 1 all-gather of the gradient phase
+    restarts = s2 // int(load_golden(name)["restart_cg_iter"])
+    warm = float(np.abs(load_golden(name)["v0"]).max()) > 0
+    n_mv = s2 + restarts + 1 + (1 if warm else 0)
+    assert n_ag == (s2 + 1) + 1
+    assert n_ar >= 1 + n_mv + (s2 + 1) + 4          # a look-ahead mat-vec that turned out unnecessary adds one
+    assert n_ar <= 1 + n_mv + (s2 + 1) + 4 + 1
+    for a, b in zip(p1, p2):
+        np.testing.assert_allclose(b, a, rtol=0, atol=(1e-10 if s1 == s2 else 1e-5) * np.abs(a).max())
+
+
+# ------------------------------------------------------------------------------- world 2 / 3 sharing the GPU, collectives by callback
+def _callbacks_worker(rank, world, port, name, q):
+    dist = _init(rank, world, port, "gloo")
+    try:
+        from cglb_amd.dist_context import DistHipContext
+        from cglb_amd.distributed import Comm, HipSymLocalOps, PyDistContext, row_partition
+        from cglb_amd.hip_context import HipContext
+        g = load_golden(name)
+        hyp = golden_hypers(g)
+        args = (float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+        M, N = hyp.Z.shape[0], g["X"].shape[0]
+        ctx = DistHipContext(g["X"], g["y"], M, int(g["kind"]), collectives="callbacks")
+        ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, hyp.Z, hyp.jitter)
+        v = torch.from_numpy(g["v0"]).to(ctx.device).clone()
+        res = ctx.objective_and_grad(v, True, *args)
+        xnew = np.random.default_rng(1).standard_normal((53, g["X"].shape[1]))
+        ctx.setup()
+        pm, pv = ctx.predict(v, xnew)
+        xr = torch.from_numpy(np.random.default_rng(2).standard_normal(N)).to(ctx.device)
+        Ax = ctx.matvec(xr).cpu().numpy()
+        z, rz = ctx.precond(xr)
+        # host-driven twin on the same GPU: same kernels, same collectives, one C call per phase
+        per, parts = row_partition(N, world)
+        shard = HipContext(g["X"], g["y"], M, int(g["kind"]), row_range=parts[rank])
+        twin = PyDistContext(HipSymLocalOps(shard), Comm())
+        twin.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, hyp.Z, hyp.jitter)
+        vt = torch.from_numpy(g["v0"]).to(ctx.device).clone()
+        rt = twin.objective_and_grad(vt, True, *args)
+        twin.setup()
+        tm, tv = twin.predict(vt, xnew)
+        q.put((rank, res.steps, res.bound, v.cpu().numpy(), res.grad, pm.cpu().numpy(), pv.cpu().numpy(), Ax, z.cpu().numpy(), rz,
+               rt.steps, rt.bound, vt.cpu().numpy(), rt.grad, tm.cpu().numpy(), tv.cpu().numpy()))
+        ctx.close(); twin.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("rbf_d8_trained", 2), ("m32_d8_restart", 2), ("m32_d3_random", 3), ("rbf_d8_warm", 3)])
+def test_library_loop_on_n_ranks_sharing_the_gpu(name, world):
+    out = _spawn(_callbacks_worker, world, (name,), world)
+    g = load_golden(name)
+    hyp = golden_hypers(g)
+    kind, X, y = int(g["kind"]), g["X"], g["y"]
+    ref = orc.objective(kind, X, y, hyp, g["v0"], True, float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]))
+    xnew = np.random.default_rng(1).standard_normal((53, X.shape[1]))
+    cov = orc.dense_cov(kind, X, hyp)
+    terms = orc.common_terms(kind, X, hyp)
+    xr = np.random.default_rng(2).standard_normal(X.shape[0])
+    zr, rzr = orc.nystrom_precond(terms.A, terms.LB, hyp.noise, xr)
+    # admissible step difference: none up to the first restart; beyond it (> 40 steps, tolerance at the round-off floor) what the oracle
+    # itself shows under perturbations of its operator at the kernel-accuracy level of the default precision
+    slack = 0
+    if ref.steps > 40:
+        slack = 1 + orc.roundoff_sensitivity(kind, X, y, hyp, g["v0"], float(g["max_error"]), int(g["max_cg_iter"]), int(g["restart_cg_iter"]),
+                                             delta=1e-13, cov=orc.dense_cov(kind, X, hyp)).steps_spread
+    for rank, steps, bound, v, grad, pm, pv, Ax, z, rz, tsteps, tbound, tv_, tgrad, tm, tv2 in out:
+        assert abs(steps - ref.steps) <= slack, (rank, steps, ref.steps, slack)
+        refg = orc.objective(kind, X, y, hyp, v, run_cg=False, with_grad=True, cov=cov)
+        assert bound == pytest.approx(refg.bound, rel=1e-11)
+        if steps == ref.steps and steps <= 40:
+            assert bound == pytest.approx(ref.bound, rel=1e-9)
+        assert bound == pytest.approx(float(g["bound"]), rel=1e-6)
+        for k in ("lengthscales", "Z"):
+            np.testing.assert_allclose(grad[k], refg.grad[k], rtol=1e-7, atol=1e-9 * max(1.0, np.abs(refg.grad[k]).max()))
+        # prediction at the rank's own v against the oracle's predictor formulae at that v (max_cg_iter=0: no further CG)
+        om, ov, _, _ = orc.predict(kind, X, y, hyp, v, xnew, max_error=1e300)
+        np.testing.assert_allclose(pm, om, rtol=0, atol=1e-9 * np.abs(om).max())
+        np.testing.assert_allclose(pv, ov, rtol=0, atol=1e-9 * np.abs(ov).max())
+        np.testing.assert_allclose(Ax, cov @ xr, rtol=0, atol=1e-11 * np.abs(cov @ xr).max())
+        np.testing.assert_allclose(z, zr, rtol=0, atol=1e-10 * np.abs(zr).max())
+        assert rz == pytest.approx(rzr, rel=1e-10)
+        # library loop == host-driven twin: same kernels, same order, same collectives
+        assert (steps, bound) == (tsteps, tbound)
+        np.testing.assert_array_equal(v, tv_)
+        np.testing.assert_array_equal(grad["Z"], tgrad["Z"])
+        np.testing.assert_array_equal(pm, tm)
+        np.testing.assert_array_equal(pv, tv2)
+    for t in out[1:]:                                        # replicated results are identical on every rank
+        assert (t[1], t[2]) == (out[0][1], out[0][2])
+        np.testing.assert_array_equal(t[3], out[0][3])
+        np.testing.assert_array_equal(t[4]["Z"], out[0][4]["Z"])
+        np.testing.assert_array_equal(t[5], out[0][5])
+
+
+# -------------------------------------------------------------------------------------------------- the backend API on 2 ranks
+def _train_worker(rank, world, port, path, tmp, q):
+    dist = _init(rank, world, port, "gloo")
+    try:
+        from cglb_amd.backend import BACKENDS, CGLBConfig, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS
+        from cglb_amd.backend.callbacks import Logger
+        from cglb_amd.dist_context import DistHipContext
+        g = dict(np.load(path))
+        be = BACKENDS["hip"]
+        be.configure_backend(logdir=tmp, keops=False)
+        be.set_default_float("fp64")
+        be.set_default_jitter("fp64")
+        kernel = "rbf" if int(g["kind"]) == 0 else "Matern32"
+        cfg = CGLBConfig(kernel=KERNEL_CONFIGS[kernel](), inducing_variable=INDUCING_VARIABLE_CONFIGS["cv"](g["init_Z"].shape[0]))
+        model = be.create_model(cfg, (g["X"], g["y"]))
+        assert isinstance(model.hip, DistHipContext) and model.hip.world == world
+        model.likelihood.noise = float(g["init_noise"])
+        model.covar_module.base_kernel.base_kernel.lengthscale = g["init_lengthscales"]
+        model.covar_module.base_kernel.outputscale = float(g["init_variance"])
+        with torch.no_grad():
+            model.mean_module.constant.copy_(torch.tensor(float(g["init_mean"]), dtype=torch.float64))
+            model.covar_module.inducing_points.copy_(torch.from_numpy(g["init_Z"]))
+        test = (g["X"][:40], g["y"][:40])
+        mfn = be.metrics_fn(model, ((g["X"], g["y"]), test))
+        logger = Logger(tmp, mfn, lambda: be.model_parameters(model), holdout_interval=5, include_feval_log=True, verbose=False)
+        losses = []
+        orig = logger.log_for_feval
+
+        def record(**entries):
+            orig(**entries)
+            losses.append(-float(model.last_bound))
+        logger.log_for_feval = record
+        results = be.optimize(model, ((g["X"], g["y"]), test), int(g["num_steps"]), logger, "scipy")
+        metrics = mfn()
+        params = {k: np.asarray(v) for k, v in be.model_parameters(model).items()}
+        q.put((rank, losses, list(logger.logs["steps-per-feval"]), [int(r.nit) for r in results], [int(r.nfev) for r in results], params,
+               {k: float(np.asarray(v)) for k, v in metrics.items()}, len(logger.logs.get("train/rmse", []))))
+        model.hip.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["train_rbf_d8_trained", "train_m32_d3_random_two_rounds"])
+def test_backend_optimize_and_metrics_on_two_ranks(case, tmp_path):
+    path = os.path.join(GOLDEN_DIR, "train", case + ".npz")
+    g = dict(np.load(path))
+    out = _spawn(_train_worker, 2, (path, str(tmp_path)), 2)
+    ref_loss, ref_steps = g["loss"], g["steps"][1:]
+    for rank, losses, steps, nit, nfev, params, metrics, n_holdout in out:
+        np.testing.assert_allclose(losses, ref_loss, rtol=1e-6, atol=1e-6, err_msg=f"rank {rank}")
+        np.testing.assert_array_equal(np.asarray(steps, dtype=np.int64), ref_steps)
+        assert nit == g["nit"].tolist() and nfev == g["nfev"].tolist()
+        np.testing.assert_allclose(params[".kernel.lengthscales"], g["final_lengthscales"], rtol=1e-5)
+        np.testing.assert_allclose(params[".inducing_variable.Z"], g["final_Z"], rtol=1e-5, atol=1e-6)
+        assert n_holdout >= 2 and all(np.isfinite(list(metrics.values())))
+    # the two ranks ran the same optimiser on identical numbers
+    assert out[0][1] == out[1][1] and out[0][6] == out[1][6]
+    for k in out[0][5]:
+        np.testing.assert_array_equal(out[0][5][k], out[1][5][k])
+    # metrics against the oracle's predictor at the final parameters (CG from the model's v at tolerance 1e-3)
+    p = out[0][5]
+    kind = "rbf" if int(g["kind"]) == 0 else "matern32"
+    hyp = orc.Hypers(p[".kernel.lengthscales"], float(p[".kernel.variance"]), float(p[".likelihood.variance"]), float(p[".mean_function.c"]),
+                     p[".inducing_variable.Z"], 1e-6)
+    X, y = g["X"], g["y"]
+    full = np.concatenate([X, X[:40]])
+    v0 = orc.objective(kind, X, y, hyp, np.zeros(len(y)), True, 1.0).v
+    fm, fv, _, _ = orc.predict(kind, X, y, hyp, v0, full, max_error=1e-3)
+    err = np.concatenate([y, y[:40]]) - fm
+    assert out[0][6]["train/rmse"] == pytest.approx(float(np.sqrt(np.mean(err[:len(y)] ** 2))), rel=1e-3)
+
+
+def test_cli_train_under_torch_distributed_run_matches_single_process(tmp_path):
+    """cli.py:60-152 for `train ... cglb` launched under torch.distributed.run with 2 ranks (sharing cuda:0 over gloo on this box; on a
+    multi-GPU node the same command line runs over RCCL): rank 0 writes the artefacts, the loss equals the single-process run."""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["-b", "hip", "-t", "fp64", "-s", "3"]
+    job = ["train", "-d", "synthetic-900-3", "-n", "8", "cglb", "-k", "Matern32", "-m", "cglb", "-i", "cv", "-M", "24"]
+    one, two = tmp_path / "one", tmp_path / "two"
+    r1 = subprocess.run([sys.executable, "-m", "cglb_amd.cli", *common, "-l", str(one), *job], env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    env2 = dict(env, CGLB_DIST_BACKEND="gloo", CGLB_SHARE_GPU="1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port()), "-m", "cglb_amd.cli", *common, "-l", str(two), *job],
+                        env=env2, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    from cglb_amd.backend import jsonio
+    a, b = jsonio.load(str(one / "results.json")), jsonio.load(str(two / "results.json"))
+    assert float(b["loss"]) == pytest.approx(float(a["loss"]), rel=1e-6)
+    assert float(b["test/rmse"]) == pytest.approx(float(a["test/rmse"]), rel=1e-5)
+    assert (two / "model.json").exists() and (two / "logs.json").exists()
+    lines = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 alone prints the result line
