@@ -387,6 +387,16 @@ int obj_phase1(cglb_ctx* c, const void* v_full, void* u_partial) {
     return CGLB_OK;
 }
 
+// Phase 1 without the mat-vec of models.py:280 (option "final_matvec" = 0): straight after a solve, w_r still holds the residual the
+// PCG recurrence carries, r = e - K v up to the rounding of its updates (exact at the start of the solve and after every restart step,
+// conjugate_gradient.py:58,72), so K v = e - r costs one vector kernel instead of N^2 pair evaluations.  The reference recomputes
+// `cov @ v`; the two differ at the level of the mat-vec's own rounding (measured: DESIGN.md section 5).
+int obj_phase1_reuse(cglb_ctx* c, void* u_partial) {
+    CGLB_TRY(launch_residual(c, c->w_Kv, c->w_e, c->w_r));                 // K v = e - r   (w_e = y - mean was the solve's right-hand side)
+    CGLB_TRY(precond_u_any(c, c->w_r, u_partial));
+    return CGLB_OK;
+}
+
 int obj_phase2(cglb_ctx* c, const void* v_full, const void* u, double* sc_partial, void* aw_partial) {
     const char* v_loc = (const char*)v_full + (size_t)c->r0 * c->esz;
     CGLB_TRY(launch_tri_apply(c, u, c->w_t));
@@ -797,7 +807,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     comm_free(c);
     void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->Xhsq, c->xah, c->wh, c->pwh, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Mtmp3, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
-                    c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk};
+                    c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk, c->uwh};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : c->k1_events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->eval_events) (void)hipEventDestroy(ev);
@@ -833,6 +843,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
         c->precision = (int)value;
     }
     else if (!strcmp(name, "drop_weighted_operand")) c->pwh_src = nullptr;  // the vector last written by cglb_vec_update_p_seg is about to change
+    else if (!strcmp(name, "final_matvec")) c->final_matvec = (int)value;
     else if (!strcmp(name, "chol_mode")) c->chol_mode = (int)value;
     else if (!strcmp(name, "grad_trsm")) c->grad_trsm = (int)value;
     else if (!strcmp(name, "precond_mode")) { c->precond_mode = (int)value; c->have_local = c->have_terms = false; }
@@ -857,11 +868,16 @@ int cglb_set_data(cglb_ctx* c, const void* X, const void* y) {
             c->xmean[d] += c->dtype == CGLB_F64 ? ((const double*)host.data())[i * c->D + d] : (double)((const float*)host.data())[i * c->D + d];
     for (int d = 0; d < c->D; ++d) c->xmean[d] /= (double)c->N;
     for (int d = 0; d < c->D; ++d) c->xrange[d] = 0.0;
-    for (int64_t i = 0; i < c->N; ++i)
+    c->xradius2 = 0.0;
+    for (int64_t i = 0; i < c->N; ++i) {
+        double r2 = 0.0;
         for (int d = 0; d < c->D; ++d) {
             const double x = c->dtype == CGLB_F64 ? ((const double*)host.data())[i * c->D + d] : (double)((const float*)host.data())[i * c->D + d];
             c->xrange[d] = std::fmax(c->xrange[d], std::fabs(x - c->xmean[d]));
+            r2 += (x - c->xmean[d]) * (x - c->xmean[d]);
         }
+        c->xradius2 = std::fmax(c->xradius2, r2);
+    }
     c->have_data = true;
     c->have_local = c->have_terms = false;
     return CGLB_OK;
@@ -890,6 +906,17 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
         // (RBF: the symmetric kernel's unweighted factor 2^(a_i + x_i.x_j) spans [-1.5 s2, 0.5 s2] octaves; fp32 exp2 range is +-126)
         const double oct_max = (c->dtype == CGLB_F32 && c->kind == CGLB_RBF) ? 200.0 : 0.95 * CGLB_EXP_FLOOR_OCT;
         c->exp_clamp = !(int_ok && oct < oct_max);
+        // Matern-3/2: the unclamped fast-level kernels keep d2 = a_i + a_j - 2 x_i.x_j positive by a bias in the row seeds instead of a
+        // clamp per pair (devmath.h).  amax = max_i a_i in hot units^2 <= hot_scale^2 s2; beyond the admissible bias the clamped variant runs.
+        c->m32_bias = 0.0;
+        if (c->kind == CGLB_MATERN32) {
+            const double hs = cglb_hot_scale(c);
+            double lmin = c->ls[0];
+            for (int d = 1; d < c->D; ++d) lmin = std::fmin(lmin, c->ls[d]);
+            const double amax = std::fmin(s2, ks * ks * c->xradius2 / (lmin * lmin)) * hs * hs;  // max_i a_i: box bound or ball bound, whichever is tighter
+            c->m32_bias = std::fmax(CGLB_M32_BIAS_FACTOR * (5.0 * c->D + 3.0) * amax, 1.0e-200);  // > 0 even when every point sits on the mean
+            if (c->m32_bias > CGLB_M32_BIAS_MAX) c->exp_clamp = true;
+        }
     }
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
     CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xh, c->xah, true));
@@ -1161,7 +1188,8 @@ int cglb_objective_and_grad(cglb_ctx* c, void* v_inout, int run_cg, double max_e
     }
     CGLB_TRY(eval_mark(c));
     double* sc = c->scal + S_SC;
-    CGLB_TRY(obj_phase1(c, v_inout, c->w_u));
+    if (run_cg && !c->final_matvec) CGLB_TRY(obj_phase1_reuse(c, c->w_u));
+    else CGLB_TRY(obj_phase1(c, v_inout, c->w_u));
     CGLB_TRY(obj_phase2(c, v_inout, c->w_u, sc, c->w_u));  // aw overwrites u after u has been consumed (stream order)
     CGLB_TRY(eval_mark(c));
     if (grad) {
@@ -1399,7 +1427,8 @@ int cglb_dist_objective_and_grad(cglb_ctx* c, void* v, int run_cg, double max_er
         CGLB_TRY(launch_sub_scalar(c, m->b, c->y, c->mean, c->N));
         CGLB_TRY(dist_pcg_impl(c, m->b, v, max_error, max_cg_iter, restart_cg_iter, steps, half_rz));
     }
-    CGLB_TRY(dist_matvec(c, v, m->Kv));                                             // models.py:280
+    if (run_cg && !c->final_matvec) CGLB_TRY(launch_residual(c, m->Kv, m->b, m->r, c->N));  // K v = e - r of the recurrence (option "final_matvec")
+    else CGLB_TRY(dist_matvec(c, v, m->Kv));                                        // models.py:280
     // phase 1 with K v given: r = e - K v on the local rows, u_partial = A_loc r
     const char* y_loc = (const char*)c->y + (size_t)c->r0 * c->esz;
     CGLB_TRY(launch_sub_scalar(c, c->w_e, y_loc, c->mean, c->nloc));

@@ -51,6 +51,7 @@ struct cglb_ctx {
     void *X = nullptr, *y = nullptr, *Z = nullptr;
     double xmean[CGLB_MAX_D] = {0};  // column means of X (centre for the Gram form)
     double xrange[CGLB_MAX_D] = {0}; // max |x - mean| per column (bounds the exponent range of the hot loops)
+    double xradius2 = 0.0;           // max_i |x_i - mean|^2 (ball bound of the row norms)
     // hypers (host)
     double ls[CGLB_MAX_D] = {0};
     double var = 1, noise = 1, mean = 0, jitter = 1e-6;
@@ -66,6 +67,7 @@ struct cglb_ctx {
     int precond_mode = 0;                // 0: stored panel A (reference form), 1: implicit K_uf products
     void *Xhsq = nullptr;  // Xh squared element-wise: second-moment operand of the Gram-form gradient pass (kernels_grad.hip)
     const void* pwh_src = nullptr;       // vector whose weighted copy pwh currently holds (set by update_p, consumed once by the next symmetric mat-vec)
+    void* uwh = nullptr;                 // u o wh: second weighted column operand of the Gram-form gradient pass (allocated on first use)
     void *wh = nullptr, *pwh = nullptr;  // RBF column weights 2^(xah_j/T) and the weighted operand p_j * wh_j of the symmetric mat-vec (length N)
     void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/T octave, T = 2^CGLB_TAB_BITS (devmath.h exp2_tab)
     double* exp_tab = nullptr;           // device table 2^(k/T) or 2^((k+1/2)/T) (CGLB_EXP_FLOOR), k < T = 2^CGLB_TAB_BITS, exponent pre-compensated (devmath.h)
@@ -125,6 +127,7 @@ struct cglb_ctx {
     double* scal = nullptr;        // device scalars (double) [64]
     double* host_scal = nullptr;   // pinned host mirror for the asynchronous read of the stop-test scalar
     hipEvent_t scal_event = nullptr;
+    int final_matvec = 0;          // 1: K v recomputed after the solve (models.py:280); 0 (default): K v = e - r from the residual the PCG recurrence carries
     int pcg_lookahead = 1;         // 1: enqueue the next mat-vec before waiting for the stop-test scalar (pcg_impl)
     double* gpart = nullptr;       // gradient partial buffers
     size_t gpart_cap = 0;
@@ -133,6 +136,7 @@ struct cglb_ctx {
     int precision = 1;  // CGLB_PREC_FAST (devmath.h): kernel values to <= 1e-13; 0 = CGLB_PREC_EXACT (~3e-16)
     int kff_variant = 2, kff_jsplit = 0, kff_rows = 4;  // 0 plain, 1 matrix-pipe Gram (fp64), 2 symmetric (default)
     bool exp_clamp = false;         // scaled operands so large that 2^x needs the range clamp (set by set_hypers)
+    double m32_bias = 0.0;          // Matern-3/2: positivity bias of the squared distance in hot units^2 (devmath.h CGLB_M32_BIAS_*; set by set_hypers)
     bool kff_skip_combine = false;  // timing only: launch the pair kernel without the slab combine
     std::string err;
 };

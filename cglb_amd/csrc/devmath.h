@@ -86,8 +86,10 @@ __device__ __forceinline__ float sqrt_pos(float x) { return __builtin_sqrtf(fmax
 // needs three instructions after the seed where sqrt(x) itself needs four (the factor 1/2 of y' = y (3 - x y^2) / 2 is the one
 // that costs an instruction; a power-of-two scale of the operands is exact).  Error 1.5 e0^2 = 2.1e-14.  At CGLB_PREC_EXACT:
 // one Goldschmidt step plus a residual correction with the first-order h (error ~ e0^3, below the rounding of the last fma), doubled.
-template <int PREC> __device__ __forceinline__ double sqrt_hot(double x) {
-    const double xs = fmax(x, 1e-280);
+// POSITIVE: the caller guarantees x > 0 (Matern-3/2 at the fast level: the row seeds of the Gram chain carry a bias that exceeds its
+// worst cancellation error, cglb_set_hypers / CGLB_M32_BIAS_*), so the clamp - one instruction per pair - is dropped.
+template <int PREC, bool POSITIVE = false> __device__ __forceinline__ double sqrt_hot(double x) {
+    const double xs = POSITIVE ? x : fmax(x, 1e-280);
     const double y = __builtin_amdgcn_rsq(xs);
     double g = xs * y;
     if (PREC != CGLB_PREC_EXACT) return g * __builtin_fma(-y, g, 3.0);
@@ -98,7 +100,16 @@ template <int PREC> __device__ __forceinline__ double sqrt_hot(double x) {
     g = __builtin_fma(d, h, g);
     return g + g;
 }
-template <int PREC> __device__ __forceinline__ float sqrt_hot(float x) { return 2.0f * __builtin_sqrtf(fmaxf(x, 0.0f)); }
+template <int PREC, bool POSITIVE = false> __device__ __forceinline__ float sqrt_hot(float x) { return 2.0f * __builtin_sqrtf(fmaxf(x, 0.0f)); }
+// Bias of the Matern-3/2 squared distance in hot units^2 (added through the row seed -(a_i + bias)/2): d2 = a_i + a_j - 2 x_i.x_j.
+// With u = 2^-53 and amax = max_i a_i: the seed and the D fused multiply-adds of the Gram chain each round a partial sum of size
+// <= 1.5 amax (error of the chain <= (D + 1) 1.5 u amax, doubled by d2 = a_j - 2 gram), and the stored norms a_i, a_j differ from the
+// exact |x|^2 of the stored operands by <= D u amax each: |d2_computed - d2_exact| <= (5 D + 3) u amax.  The bias is 1.5x that bound.
+// A coincident pair then evaluates to kappa = 1 - 2 (ln2/256)^2 bias instead of 1; the bias is only used while that stays below 3e-13
+// (bias <= 2e-8; the headline shape has 1.2e-8), otherwise the clamped variant runs.  Distinct points sit at d2 >~ 1 hot unit^2 and
+// do not see it.
+#define CGLB_M32_BIAS_FACTOR (1.5 * 1.1102230246251565e-16)   // bias = FACTOR * (5 D + 3) * amax
+#define CGLB_M32_BIAS_MAX 2.0e-8
 
 __device__ __forceinline__ double tfma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float tfma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -266,7 +277,8 @@ template <typename T, int KIND, bool CLAMP> __device__ __forceinline__ T kappa_f
 // Two-phase evaluation for software-pipelined loops: `begin` does the range reductions of the R rows a lane owns and issues the R
 // table reads, `poly` is independent of the reads, `end` consumes them - so a loop can keep R lookups in flight.
 template <typename T> struct KappaPend { T s; T lin; int ni; T tabv; };
-// FOLDED (RBF only): the column norm a_j is not added here - the caller has folded 2^(a_j/T) into the column operand.
+// FOLDED, RBF: the column norm a_j is not added here - the caller has folded 2^(a_j/T) into the column operand.
+// FOLDED, Matern-3/2: the caller's row seeds carry the positivity bias (sqrt_hot<PREC, true>: no clamp).
 template <typename T, int KIND, bool CLAMP, bool FOLDED, int PREC, int R>
 __device__ __forceinline__ void kappa_hot_begin_batch(const T (&gram)[R], T aj, const double* __restrict__ tab, KappaPend<T> (&kp)[R]) {
     if constexpr (sizeof(T) == 8) {
@@ -279,7 +291,7 @@ __device__ __forceinline__ void kappa_hot_begin_batch(const T (&gram)[R], T aj, 
                 if (CLAMP) x[r] = tmax<double>(x[r], -CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE);
             } else {
                 const double d2 = tfma<double>(-2.0, gram[r], aj);
-                x[r] = sqrt_hot<PREC>(d2);
+                x[r] = sqrt_hot<PREC, FOLDED>(d2);
                 kp[r].lin = tfma<double>(x[r], CGLB_LN2 / CGLB_HOT_UNITS, 1.0);
                 if (CLAMP) x[r] = tmin<double>(x[r], CGLB_EXP_FLOOR_OCT * CGLB_TAB_SIZE);
             }

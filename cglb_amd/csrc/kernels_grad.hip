@@ -95,12 +95,18 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
 #define GRAD_TR_LD 65  // leading dimension of a wave's 8 x 64 transposition scratch (odd: the column reads spread over the banks)
 template <typename T, int KIND, int DP, int R, int PREC, bool CLAMP>
 __global__ __launch_bounds__(256, (DP == CGLB_GRAM_W3_DP ? 3 : 1)) void grad_kff_gram_kernel(const T* __restrict__ Xh, const T* __restrict__ Xhsq, const T* __restrict__ ah,
-                                                            const T* __restrict__ u, const T* __restrict__ v, int64_t row0, int64_t n,
+                                                            const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ uc,
+                                                            const T* __restrict__ vc, int64_t row0, int64_t n,
                                                             int64_t jchunk, int64_t blk0, int rb_stride, int rb_offset,
-                                                            double* __restrict__ part, const double* __restrict__ exp_tab) {
+                                                            double* __restrict__ part, const double* __restrict__ exp_tab, T bias) {
     __shared__ double smem[16];
     __shared__ double tab[CGLB_TAB_SIZE];
     load_exp_table(tab, exp_tab);
+    // RBF, unclamped range: folded column norm as in the symmetric mat-vec - h_ij = 2^(a_i + x_i.x_j) w_j with w_j = 2^(a_j) carried by the
+    // column-side copies uc = u o w, vc = v o w of the two vectors (the row side uses u, v themselves), so the per-pair add of a_j is dropped
+    constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP && sizeof(T) == 8;
+    // Matern-3/2, fast level, unclamped range: positivity bias in the row seeds instead of a clamp per pair (devmath.h CGLB_M32_BIAS_*)
+    constexpr bool BIASED = (KIND != CGLB_RBF) && !CLAMP && PREC == CGLB_PREC_FAST && sizeof(T) == 8;
     const int64_t rblock = ((int64_t)blockIdx.x * rb_stride + rb_offset) * (256 * R);  // cyclic over ranks when rb_stride > 1
     const int64_t rbase = rblock + threadIdx.x;
     __shared__ T trbuf[4 * 8 * GRAD_TR_LD];
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256, (DP == CGLB_GRAM_W3_DP ? 3 : 1)) void grad_kff
         }
         S0[k] = 0;
         const T a = ah[row0 + rr];
-        aseed[k] = (KIND == CGLB_RBF) ? a : T(-0.5) * a;
+        aseed[k] = (KIND == CGLB_RBF) ? a : (BIASED ? T(-0.5) * (a + bias) : T(-0.5) * a);
         // padded rows carry zero weight; Matern-3/2: h = 3 * 2^(-r), the factor 3 rides in the row weights
         const T hscale = (KIND == CGLB_RBF) ? T(1) : T(3);
         ui[k] = row < n ? hscale * u[row0 + rr] : T(0);
@@ -142,9 +148,9 @@ __global__ __launch_bounds__(256, (DP == CGLB_GRAM_W3_DP ? 3 : 1)) void grad_kff
             t[jj] = 0;
             if (jc < j1) {  // wave-uniform: only the last batch of a chunk is short
                 const int64_t j = row0 + jc;
-                const T vj = v[j];
-                const T wu = (jc >= sym_from) ? u[j] : T(0);  // wave-uniform
-                const T aj = ah[j];
+                const T vj = vc[j];
+                const T wu = (jc >= sym_from) ? uc[j] : T(0);  // wave-uniform
+                const T aj = FOLD ? T(0) : ah[j];
                 T xj[DP];
 #pragma unroll
                 for (int d = 0; d < DP; ++d) xj[d] = Xh[j * DP + d];
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256, (DP == CGLB_GRAM_W3_DP ? 3 : 1)) void grad_kff
                     T g = aseed[k];
 #pragma unroll
                     for (int d = 0; d < DP; ++d) g = tfma<T>(xi[k][d], xj[d], g);
-                    earg[k] = (KIND == CGLB_RBF) ? g + aj : sqrt_hot<PREC>(tfma<T>(T(-2), g, aj));  // RBF: exponent; Matern: r (exponent -r)
+                    earg[k] = (KIND == CGLB_RBF) ? (FOLD ? g : g + aj) : sqrt_hot<PREC, BIASED>(tfma<T>(T(-2), g, aj));  // RBF: exponent; Matern: r (exponent -r)
                 }
                 exp2_tab_batch<CLAMP, KIND != CGLB_RBF, PREC, R>(earg, tab, h);  // CLAMP: exponents beyond the table's range (set_hypers decides)
                 T cj = 0;
@@ -266,6 +272,27 @@ static int ensure_gpart(cglb_ctx* c, size_t need) {
 
 static inline double kscale_of(const cglb_ctx* c) { return (c->kind == CGLB_RBF) ? sqrt(CGLB_LOG2E) : CGLB_SQRT3 * CGLB_LOG2E; }
 
+// column-side copies of the two vectors of the bilinear form for the folded column norm (RBF, unclamped range): vw = v o wh over all
+// n_v entries, uw[off + i] = u[i] wh[off + i] over the n_u entries the caller holds.  vw lives in the mat-vec's pwh buffer.
+template <typename T>
+__global__ __launch_bounds__(256) void grad_weight_kernel(const T* __restrict__ v, int64_t n_v, const T* __restrict__ u, int64_t off, int64_t n_u,
+                                                          const T* __restrict__ wh, T* __restrict__ vw, T* __restrict__ uw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_v) vw[i] = v[i] * wh[i];
+    if (i < n_u) uw[off + i] = u[i] * wh[off + i];
+}
+static int grad_fold_operands(cglb_ctx* c, const void* v_full, const void* u, int64_t off, int64_t n_u, bool* fold) {
+    *fold = c->kind == CGLB_RBF && !c->exp_clamp && c->dtype == CGLB_F64 && c->have_hypers;
+    if (!*fold) return CGLB_OK;
+    if (!c->uwh) HIP_CHECK(c, hipMalloc(&c->uwh, (size_t)c->N * c->esz));
+    c->pwh_src = nullptr;  // pwh no longer holds the weighted direction of the PCG loop
+    const int64_t n = c->N > n_u ? c->N : n_u;
+    hipLaunchKernelGGL((grad_weight_kernel<double>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double*)v_full, c->N,
+                       (const double*)u, off, n_u, (const double*)c->wh, (double*)c->pwh, (double*)c->uwh);
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
 // out_dl[d] (device double[D], overwritten) = sum_{i local, j} u_i dK_ij/dl_d v_j
 int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double* out_dl) {
     ScaleParams sp;
@@ -281,6 +308,8 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
     // fp32 keeps direct differences (no digits to spare); the clamped exponent range (large scaled coordinates: wide D at short
     // lengthscales, e.g. the reference's initial l = 1 at D >= 17) runs the same Gram form with the range clamp of the 2^x
     const bool use_gram = c->grad_gram && c->dtype == CGLB_F64;
+    bool fold = false;
+    if (use_gram) CGLB_TRY(grad_fold_operands(c, v_full, u_local, c->r0, c->nloc, &fold));
     const int R = c->Dp <= 8 ? 2 : 1;
     const int Rg = CGLB_GRAM_ROWS_OF(c->Dp);  // the Gram-form kernel (square range only)
     // three column ranges: the square block (symmetric form) and the shard's off-diagonal ranges [0,r0), [r1,N)
@@ -313,8 +342,9 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
                        (const T*)u_local, r.ncols, r.jchunk, blk0, 1, 0, c->gpart, (const double*)c->exp_tab)
 #define GG_LAUNCH1(RR, CL)                                                                                                            \
     hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR, PREC, CL>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq, \
-                       (const T*)c->xah, (const T*)u_local - c->r0, (const T*)v_full, c->r0, c->nloc, r.jchunk, blk0, 1, 0, c->gpart,     \
-                       (const double*)c->exp_tab)
+                       (const T*)c->xah, (const T*)u_local - c->r0, (const T*)v_full, (CL || !fold) ? (const T*)u_local - c->r0 : (const T*)c->uwh,       \
+                       (CL || !fold) ? (const T*)v_full : (const T*)c->pwh, c->r0, c->nloc, r.jchunk, blk0, 1, 0, c->gpart,               \
+                       (const double*)c->exp_tab, (T)c->m32_bias)
 #define GG_LAUNCH(RR) do { if (c->exp_clamp) { GG_LAUNCH1(RR, true); } else { GG_LAUNCH1(RR, false); } } while (0)
         if (r.sym && use_gram) {
             // u_local is indexed by global row inside the kernel (row0 + local), hence the shifted base pointer
@@ -343,6 +373,8 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
         sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
     }
     const bool use_gram = c->grad_gram && c->dtype == CGLB_F64;
+    bool fold = false;
+    if (use_gram) CGLB_TRY(grad_fold_operands(c, v_full, u_full, 0, c->N, &fold));
     const int R = use_gram ? CGLB_GRAM_ROWS_OF(c->Dp) : (c->Dp <= 8 ? 2 : 1);
     const int64_t nb = (c->N + 256 * R - 1) / (256 * R);
     const int64_t bx = c->par_rank < nb ? (nb - c->par_rank + c->par_world - 1) / c->par_world : 0;
@@ -365,8 +397,9 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
                        c->par_world, c->par_rank, c->gpart, (const double*)c->exp_tab)
 #define GGC_LAUNCH1(RR, CL)                                                                                                          \
     hipLaunchKernelGGL((grad_kff_gram_kernel<T, KIND, DP, RR, PREC, CL>), grid, dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->Xhsq, \
-                       (const T*)c->xah, (const T*)u_full, (const T*)v_full, (int64_t)0, c->N, jchunk, (int64_t)0, c->par_world, c->par_rank, \
-                       c->gpart, (const double*)c->exp_tab)
+                       (const T*)c->xah, (const T*)u_full, (const T*)v_full, (CL || !fold) ? (const T*)u_full : (const T*)c->uwh,                   \
+                       (CL || !fold) ? (const T*)v_full : (const T*)c->pwh, (int64_t)0, c->N, jchunk, (int64_t)0, c->par_world, c->par_rank, \
+                       c->gpart, (const double*)c->exp_tab, (T)c->m32_bias)
 #define GGC_LAUNCH(RR) do { if (c->exp_clamp) { GGC_LAUNCH1(RR, true); } else { GGC_LAUNCH1(RR, false); } } while (0)
     if (use_gram) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, GGC_LAUNCH(CGLB_GRAM_ROWS_OF(DP)))); }
     else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); })); }

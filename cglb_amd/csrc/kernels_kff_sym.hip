@@ -50,8 +50,10 @@ typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane
 template <typename T, int KIND, int DP, int R, bool CLAMP, int PREC>
 __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* __restrict__ xa, const T* __restrict__ p, const T* __restrict__ pc,
                                              int64_t row0, int64_t n, int64_t chunk, int64_t rb, int64_t k, int64_t cslot, int64_t prow_ld,
-                                             T* __restrict__ Prow, T* __restrict__ cs, T* __restrict__ tr, const double* __restrict__ tab, int lane) {
+                                             T* __restrict__ Prow, T* __restrict__ cs, T* __restrict__ tr, const double* __restrict__ tab, int lane, T bias) {
     constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP;
+    // Matern-3/2, fast level, unclamped range: squared distances kept positive by a bias in the row seeds instead of a clamp per pair
+    constexpr bool BIASED = (KIND != CGLB_RBF) && !CLAMP && PREC == CGLB_PREC_FAST && sizeof(T) == 8;
     constexpr int RBROWS = 64 * R;
     const int64_t rbase = rb * RBROWS;
     // fp32: rows in pairs, so that the Gram chain and the two accumulations run as v_pk_fma_f32 (4.8 nominal cycles per pair of
@@ -72,7 +74,7 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
             else xi[r % RU][d] = v;
         }
         const T a = xa[row0 + rr];
-        ai[r] = (KIND == CGLB_RBF) ? a : T(-0.5) * a;
+        ai[r] = (KIND == CGLB_RBF) ? a : (BIASED ? T(-0.5) * (a + bias) : T(-0.5) * a);
         pr[r] = row < n ? p[row0 + rr] : T(0);
         acc[r] = 0;
     }
@@ -151,7 +153,7 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
                 __builtin_amdgcn_sched_barrier(0);
             }
             KappaPend<T> kp[R];
-            kappa_hot_begin_batch<T, KIND, CLAMP, FOLD, PREC, R>(gram, aj, tab, kp);
+            kappa_hot_begin_batch<T, KIND, CLAMP, FOLD || BIASED, PREC, R>(gram, aj, tab, kp);
             __builtin_amdgcn_sched_barrier(0);  // all R table reads are in flight here ...
 #pragma unroll
             for (int r = 0; r < R; ++r) kappa_hot_poly<T, KIND, PREC>(kp[r]);
@@ -257,7 +259,7 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
             T gram = ai[r];
 #pragma unroll
             for (int d = 0; d < DP; ++d) gram = tfma<T>(PACKED ? (T)xi2[(r / 2) % RP][d][r % 2] : xi[r % RU][d], xj[d], gram);
-            const T kap = kappa_hot_single<T, KIND, CLAMP, FOLD, PREC>(gram, aj, tab);  // FOLD: the weight is in pj / applied below
+            const T kap = kappa_hot_single<T, KIND, CLAMP, FOLD || BIASED, PREC>(gram, aj, tab);  // FOLD: the weight is in pj / applied below
             acc[r] = tfma<T>(kap, pj, acc[r]);
             tj = tfma<T>(kap, pr[r], tj);
         }
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : CGLB_SYM_WAVES(DP, R))) 
                                                       const T* __restrict__ pw, const T* __restrict__ wcol,
                                                       int64_t row0, int64_t n, int64_t chunk, const int2* __restrict__ items,
                                                       const int2* __restrict__ groups, int rb_stride, int64_t prow_ld, T* __restrict__ Prow,
-                                                      T* __restrict__ Pcol, const double* __restrict__ exp_tab) {
+                                                      T* __restrict__ Pcol, const double* __restrict__ exp_tab, T bias) {
     __shared__ double tab[CGLB_TAB_SIZE];
     __shared__ T csum[4 * SYM_CHUNK_MAX];
     __shared__ T trbuf[(R == 1 || CGLB_SYM_TR_REG) ? 1 : 4 * 8 * SYM_TR_LD];  // transposition scratch of the four waves (unused for R == 1)
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : CGLB_SYM_WAVES(DP, R))) 
     if (__builtin_amdgcn_readfirstlane(it.x) >= 0) {
         const int64_t rb = __builtin_amdgcn_readfirstlane(it.x), k = __builtin_amdgcn_readfirstlane(it.y);
         const int64_t cslot = rb / rb_stride;  // compact slot: with a cyclic rank distribution only every rb_stride-th block is here
-        kff_sym_item<T, KIND, DP, R, CLAMP, PREC>(Xs, xa, p, pc, row0, n, chunk, rb, k, cslot, prow_ld, Prow, cs, trbuf + ((R == 1 || CGLB_SYM_TR_REG) ? 0 : wave * 8 * SYM_TR_LD), tab, lane);
+        kff_sym_item<T, KIND, DP, R, CLAMP, PREC>(Xs, xa, p, pc, row0, n, chunk, rb, k, cslot, prow_ld, Prow, cs, trbuf + ((R == 1 || CGLB_SYM_TR_REG) ? 0 : wave * 8 * SYM_TR_LD), tab, lane, bias);
     }
     __syncthreads();
     const int64_t gslot = __builtin_amdgcn_readfirstlane(grp.x), k = __builtin_amdgcn_readfirstlane(grp.y);
@@ -576,11 +578,11 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
             if (c->exp_clamp)
                 hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, true, PREC>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah,
                                    p_full, (const T*)nullptr, (const T*)nullptr, row0, n, chunk, items_dev, groups_dev, world, prow_ld, Prow,
-                                   Pcol, (const double*)c->exp_tab);
+                                   Pcol, (const double*)c->exp_tab, (T)0);
             else
                 hipLaunchKernelGGL((kff_sym_kernel<T, KIND, DP, R, false, PREC>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Xh, (const T*)c->xah,
                                    p_full, (const T*)c->pwh, (const T*)c->wh, row0, n, chunk, items_dev, groups_dev, world, prow_ld, Prow,
-                                   Pcol, (const double*)c->exp_tab);
+                                   Pcol, (const double*)c->exp_tab, (T)c->m32_bias);
         });
         CGLB_LAUNCH_CHECK(c);
         if (e1) HIP_CHECK(c, hipEventRecord(e1, c->stream));

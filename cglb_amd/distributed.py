@@ -350,6 +350,9 @@ class SymShardedCGLB:
         self.grad = z(self.D + 3 + self.M * self.D, torch.float64)
         ops.set_parallel(G, self.comm.rank)
         self.lookahead = True
+        # False (default, like the library's option "final_matvec" = 0): after a solve K v = b - r comes from the residual the PCG
+        # recurrence carries instead of one more mat-vec + all-reduce (models.py:280 recomputes it; difference at round-off level)
+        self.final_matvec = False
         self._pinned = None
         self._event = None
 
@@ -466,7 +469,10 @@ class SymShardedCGLB:
         steps, half = 0, float("nan")
         if run_cg:
             steps, half = self.pcg(max_error, max_cg_iter, restart_cg_iter)
-        self.matvec(self.v, self.Kv)                                          # models.py:280
+        if run_cg and not self.final_matvec:
+            ops.vec_residual(self.N, self.Kv, self.b, self.r)                 # K v = e - r
+        else:
+            self.matvec(self.v, self.Kv)                                      # models.py:280
         ops.obj_phase1_kv(self.Kv[self.r0:self.r1], self.u)
         comm.allreduce(self.u)
         ops.obj_phase2(self.v, self.u, self.sc, self.aw)

@@ -249,6 +249,9 @@ int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
  * "grad_trsm" (gradient algebra against L = chol(K_uu): 0 products with the explicit inverse, 1 backward-stable triangular solves, 2 = default:
  *  the solves whenever diag(L) spreads over more than two decades, i.e. K_uu is ill conditioned) |
  * "precision" (1, default: kernel values to <= 1e-13 relative - degree-3 table polynomial, one-step square root; 0: ~3e-16) ...;
+ * "final_matvec" (cglb_objective_and_grad after a solve: 1 recomputes K v with a mat-vec like models.py:280; 0, the default, takes K v = e - r
+ *  from the residual r the PCG recurrence carries - exact at the start of a solve and after every restart step; measured difference at the
+ *  headline shape: bound <= 3e-15 relative, gradient <= 1e-10 of its largest entry, one N^2 pass saved per evaluation) |
  * "drop_weighted_operand" (any value: forget the pre-weighted copy cglb_vec_update_p_seg made of its p - for callers that modify p before the next mat-vec);
  * returns CGLB_ERR_BAD_ARG if unknown. */
 int cglb_set_option(cglb_ctx* ctx, const char* name, int64_t value);

@@ -108,7 +108,7 @@ def test_library_loop_over_rccl_world1_equals_fused_path(name):
     # + u, sc, aw, grad (4) all-reduces and 1 all-gather of the gradient phase
     restarts = s2 // int(load_golden(name)["restart_cg_iter"])
     warm = float(np.abs(load_golden(name)["v0"]).max()) > 0
-    n_mv = s2 + restarts + 1 + (1 if warm else 0)
+    n_mv = s2 + restarts + (1 if warm else 0)       # K v after the solve comes from the recurrence residual (option "final_matvec" = 0)
     assert n_ag == (s2 + 1) + 1
     assert n_ar >= 1 + n_mv + (s2 + 1) + 4          # a look-ahead mat-vec that turned out unnecessary adds one
     assert n_ar <= 1 + n_mv + (s2 + 1) + 4 + 1

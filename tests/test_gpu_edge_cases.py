@@ -248,10 +248,56 @@ def test_consecutive_cold_start_solves_on_one_context(kind):
         ref_steps = st.steps
         assert abs(steps - ref_steps) <= (0 if max_iter == 7 else 1), (trial, steps, ref_steps)
         if steps == ref_steps:
-            np.testing.assert_allclose(v.cpu().numpy(), ref_v, rtol=0, atol=1e-8 * np.abs(ref_v).max(), err_msg=f"solve {trial}")
+            # 7 steps: round-off only.  The run to convergence (tens of steps behind a 16-point preconditioner, stop at 1/2 r^T P r <= 1e-8)
+            # pins v no better than the stopping tolerance does: |dv| <~ |K^-1| |r|
+            tol_v = 1e-8 if max_iter == 7 else 1e-3
+            np.testing.assert_allclose(v.cpu().numpy(), ref_v, rtol=0, atol=tol_v * np.abs(ref_v).max(), err_msg=f"solve {trial}")
     # a cold-start evaluation right after a solve on the same context
     vz = torch.zeros(N, dtype=torch.float64, device=ctx.device)
     res = ctx.objective_and_grad(vz, True, 1.0, 100, 40, with_grad=False)
     ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, 1.0, 100, 40)
-    assert res.steps == ref.steps and res.bound == pytest.approx(ref.bound, rel=1e-10)
+    assert res.steps == ref.steps and res.bound == pytest.approx(ref.bound, rel=1e-6)     # 24 steps behind a 16-point preconditioner
+    assert res.bound == pytest.approx(orc.objective(kind, X, y, hyp, vz.cpu().numpy(), run_cg=False).bound, rel=1e-11)
+    # ... and the used context must give exactly what a fresh one gives: nothing of the earlier solves leaks into this one
+    fresh = HipContext(X, y, M, kind)
+    fresh.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+    vf = torch.zeros(N, dtype=torch.float64, device=fresh.device)
+    rf = fresh.objective_and_grad(vf, True, 1.0, 100, 40, with_grad=False)
+    assert (rf.steps, rf.bound) == (res.steps, res.bound)
+    np.testing.assert_array_equal(vf.cpu().numpy(), vz.cpu().numpy())
+    fresh.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+def test_kv_from_the_recurrence_residual_equals_the_recomputed_one(kind):
+    """Option "final_matvec": after a solve the evaluation takes K v = e - r from the residual the PCG recurrence carries (default)
+    instead of recomputing `cov @ v` (models.py:280, option value 1).  The two agree to the rounding of the mat-vec itself - cold
+    start, warm start, a > 40-step solve that crosses the restart - and both agree with the oracle's assembly at the same v."""
+    from cglb_amd.hip_context import HipContext
+    N, D, M = 3000, 8, 24
+    X, y, Z = orc.synthetic_problem(N, D, M, seed=8)
+    hyp = orc.trained_like_hypers(D, Z)
+    hyp.noise = 0.02
+    out = {}
+    for fm in (1, 0):
+        ctx = HipContext(X, y, M, kind)
+        ctx.set_option("final_matvec", fm)
+        ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+        v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
+        cold = ctx.objective_and_grad(v, True, 1e-3, 100, 40)
+        v_cold = v.cpu().numpy().copy()
+        ctx.set_hypers(hyp.lengthscales * 1.03, hyp.variance, hyp.noise * 1.05, hyp.mean + 0.01, Z, hyp.jitter)
+        warm = ctx.objective_and_grad(v, True, 1e-3, 100, 40)
+        out[fm] = (cold, v_cold, warm, v.cpu().numpy().copy())
+        ctx.close()
+    (c1, vc1, w1, vw1), (c0, vc0, w0, vw0) = out[1], out[0]
+    assert c1.steps > 40 and c0.steps == c1.steps and w0.steps == w1.steps
+    np.testing.assert_array_equal(vc0, vc1)                      # the solve itself is untouched by the option
+    for a, b in ((c0, c1), (w0, w1)):
+        assert a.bound == pytest.approx(b.bound, rel=1e-12) and a.lower == pytest.approx(b.lower, rel=1e-11)
+        for k in ("lengthscales", "Z"):
+            np.testing.assert_allclose(a.grad[k], b.grad[k], rtol=0, atol=1e-9 * np.abs(b.grad[k]).max())
+    ref = orc.objective(kind, X, y, hyp, vc0, run_cg=False, with_grad=True)
+    assert c0.bound == pytest.approx(ref.bound, rel=1e-11)
+    np.testing.assert_allclose(c0.grad["lengthscales"], ref.grad["lengthscales"], rtol=1e-7)

@@ -144,3 +144,38 @@ def test_precision_levels_agree(name):
     for key in ("lengthscales", "variance", "noise", "Z"):
         refg = g["g_" + key]
         np.testing.assert_allclose(np.asarray(res.grad[key]), refg, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(refg).max()), err_msg=key)
+
+
+import glob as _glob
+import os as _os
+
+PREDICT_CASES = sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "predict", "*.npz")))
+
+
+@pytest.mark.parametrize("path", PREDICT_CASES, ids=[_os.path.splitext(_os.path.basename(p))[0] for p in PREDICT_CASES])
+def test_predict_cg_vs_reference_solver_driven_golden(path):
+    """PredictCG (models.py:289-354) through the backend classes against tests/golden/predict/*.npz (the reference's own solver at
+    tolerance 1e-3, warm-started at the model's v; predictor algebra restated in torch - oracle/gen_predict_golden.py)."""
+    import torch
+    from cglb_amd.backend.models import CGLB, BaseKernel, GaussianLikelihood, InducingPointKernel, PredictCG, ScaleKernel
+    p = dict(np.load(path))
+    g = load_golden(str(p["source"]))
+    hyp = golden_hypers(g)
+    kind = "rbf" if int(g["kind"]) == 0 else "matern32"
+    base = BaseKernel(kind, ard_num_dims=g["X"].shape[1])
+    base.lengthscale = hyp.lengthscales
+    scale = ScaleKernel(base)
+    scale.outputscale = hyp.variance
+    lik = GaussianLikelihood(lower_bound=1e-6)
+    lik.noise = hyp.noise
+    model = CGLB((g["X"], g["y"]), lik, InducingPointKernel(scale, hyp.Z))
+    with torch.no_grad():
+        model.mean_module.constant.copy_(torch.tensor(hyp.mean, dtype=torch.float64))
+        model.v_vec.copy_(torch.from_numpy(g["v"]).reshape(-1, 1))            # the model's v after its training solve
+    pred = PredictCG(model)
+    f_mean, f_var = pred(torch.from_numpy(p["xnew"]))
+    np.testing.assert_allclose(pred.v_vec.cpu().numpy().reshape(-1), p["new_v"], rtol=0, atol=1e-8 * np.abs(p["new_v"]).max())
+    np.testing.assert_allclose(f_mean.cpu().numpy().reshape(-1), p["f_mean"], rtol=0, atol=1e-8 * np.abs(p["f_mean"]).max())
+    np.testing.assert_allclose(f_var.cpu().numpy().reshape(-1), p["f_var"], rtol=0, atol=1e-8 * np.abs(p["f_var"]).max())
+    np.testing.assert_array_equal(model.v_vec.cpu().numpy().reshape(-1), g["v"])      # the model's own v is not touched (models.py:294)
+    model.hip.close()

@@ -113,3 +113,43 @@ def test_restart_keeps_residual_consistent():
     r = err - cov @ v
     _, rz = orc.nystrom_precond(terms.A, terms.LB, hyp.noise, r)
     assert 0.5 * rz == pytest.approx(stats.residual_error, rel=1e-9, abs=1e-25)
+
+
+import glob as _glob
+import os as _os
+
+PREDICT_CASES = sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "predict", "*.npz")))
+
+
+@pytest.mark.parametrize("path", PREDICT_CASES, ids=[_os.path.splitext(_os.path.basename(p))[0] for p in PREDICT_CASES])
+def test_predict_matches_reference_solver_driven_restatement(path):
+    """PredictCG.forward (models.py:307-354): the numpy oracle against tests/golden/predict/*.npz, made by a torch restatement of the
+    predictor algebra that calls the REFERENCE's own ConjugateGradient(max_error=1e-3) / NystromPreconditioner, warm-started at the
+    model's v (oracle/gen_predict_golden.py)."""
+    p = dict(np.load(path))
+    g = load_golden(str(p["source"]))
+    hyp = golden_hypers(g)
+    f_mean, f_var, new_v, stats = orc.predict(int(g["kind"]), g["X"], g["y"], hyp, g["v"], p["xnew"], max_error=1e-3)
+    assert stats.steps == int(p["steps"])
+    assert stats.residual_error == pytest.approx(float(p["residual_error"]), rel=1e-6)
+    np.testing.assert_allclose(new_v, p["new_v"], rtol=0, atol=1e-9 * np.abs(p["new_v"]).max())
+    np.testing.assert_allclose(f_mean, p["f_mean"], rtol=0, atol=1e-9 * np.abs(p["f_mean"]).max())
+    np.testing.assert_allclose(f_var, p["f_var"], rtol=0, atol=1e-9 * np.abs(p["f_var"]).max())
+
+
+def test_roundoff_sensitivity_tells_stable_from_chaotic_solves():
+    """oracle.roundoff_sensitivity (the derived parity criterion): a short well-preconditioned solve is
+    reproducible under eps-sized perturbations of its operator, a > 40-step solve at a tolerance near the round-off floor is not."""
+    g = load_golden("rbf_d8_init")
+    s = orc.roundoff_sensitivity(int(g["kind"]), g["X"], g["y"], golden_hypers(g), g["v0"], 1.0, 100, 40)
+    assert s.steps == int(g["steps"]) and s.steps_spread == 0 and s.bound_spread <= 1e-11 * abs(s.bound)
+    assert len(s.history) == s.steps + 1 and s.history[-1] <= 1.0 < s.history[-2]
+    g = load_golden("rbf_d8_restart")
+    s = orc.roundoff_sensitivity(int(g["kind"]), g["X"], g["y"], golden_hypers(g), g["v0"], float(g["max_error"]), 100, 40)
+    assert s.steps > 40 and s.stat_rel_spread[-1] > 1e-6        # the stop statistic itself is only known to a few digits there
+    hyp = golden_hypers(g)
+    terms = orc.common_terms(int(g["kind"]), g["X"], hyp)
+    cov = orc.dense_cov(int(g["kind"]), g["X"], hyp)
+    w, _ = orc.nystrom_precond(terms.A, terms.LB, hyp.noise, (g["y"] - hyp.mean) - cov @ g["v"])
+    floor = orc.grad_roundoff_spread(int(g["kind"]), g["X"], hyp, g["v"], w)
+    assert set(floor) == {"lengthscales", "variance", "noise", "mean", "Z"} and all(v >= 0 for v in floor.values())
