@@ -334,8 +334,12 @@ def main():
     # Counter-derived figures come from committed rocprofv3 --pmc passes of this same command (tools/pmc_collect.sh); they are
     # quoted only for the workload they were collected on and name their source file.
     traffic_k1 = traffic_prec = executed = None
-    pmc_hbm = os.path.join("profiles", "r02_pmc_hbm_traffic.json")
-    pmc_sq = os.path.join("profiles", "r02_pmc_sq_counters.json")
+    def newest(pattern):   # the most recent round's committed counter summary (profiles/rNN_*.json)
+        import glob
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        return os.path.relpath(found[-1], ROOT) if found else os.path.join("profiles", pattern)
+    pmc_hbm = newest("r[0-9][0-9]_pmc_hbm_traffic.json")
+    pmc_sq = newest("r[0-9][0-9]_pmc_sq_counters.json")
     on_profiled_workload = world == 1 and (N, D, M, kind) == (100_000, 8, 1024, "rbf")
     if on_profiled_workload and os.path.exists(os.path.join(ROOT, pmc_hbm)):
         pk = json.load(open(os.path.join(ROOT, pmc_hbm)))["kernels"]

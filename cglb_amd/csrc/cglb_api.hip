@@ -434,11 +434,24 @@ int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const voi
                         &zero, (T*)c->Mtmp, M));
     hipLaunchKernelGGL((trace_kernel<T>), dim3(1), dim3(256), 0, c->stream, (const T*)c->Mtmp, M, c->scal + S_TRBINV);
     // c = Kuu^-1 Kuf w = sigma L^-T (A w); mhalf = -c/2
-    const bool use_inv = c->grad_trsm == 0 || (c->grad_trsm == 2 && c->L_diag_ratio <= CGLB_LINV_DIAG_RATIO);
+    // grad_trsm: 0 products with the explicit L^-1; 1 rocBLAS trsm / trsv; 2 (default) the products followed by ONE step of iterative
+    // refinement against L itself (x += L^-1 (b - L x): two more M^3 GEMMs per solve, ~50 us each at M = 1024, against 270 us for a
+    // rocBLAS trsm with an M x M right-hand side) - the forward error of a product with an explicit inverse is ~ eps cond(L) |L^-1||b|,
+    // one refinement step brings it to that of a backward-stable solve, ~ eps cond(L) |x| (tools/zgrad_owner.py, tools/grad_trsm_ab.py)
+    const bool use_inv = c->grad_trsm != 1;
+    const bool refine = c->grad_trsm == 2;
+    const T minus_one = -1;
     if (use_inv) {
         CGLB_TRY(ensure_Linv<T>(c));
         if (!c->Mtmp3) CGLB_TRY(dalloc(c, &c->Mtmp3, (size_t)M * M * c->esz));
+        if (refine && !c->Mtmp4) CGLB_TRY(dalloc(c, &c->Mtmp4, (size_t)M * M * c->esz));
         CGLB_TRY(launch_tri_rowdot(c, c->Linv, aw, 0, c->w_t2));  // (L^-T x)_i = column i of L^-1 (contiguous) . x
+        if (refine) {
+            CGLB_TRY(launch_tri_rowdot(c, c->Lc, c->w_t2, 0, c->w_q));       // L^T x: column i of L (contiguous) . x
+            CGLB_TRY(launch_residual(c, c->w_t, aw, c->w_q, M));              // aw - L^T x
+            CGLB_TRY(launch_tri_rowdot(c, c->Linv, c->w_t, 0, c->w_q));
+            CGLB_TRY(launch_axpy(c, c->w_t2, 1.0, c->w_q, M));
+        }
     } else {
         HIP_CHECK(c, hipMemcpyAsync(c->w_t2, aw, (size_t)M * c->esz, hipMemcpyDeviceToDevice, c->stream));
         BLAS_CHECK(c, xtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, (const T*)c->Lc, M, (T*)c->w_t2, 1));
@@ -453,6 +466,14 @@ int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const voi
     if (use_inv) {
         BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &inv_sigma, (const T*)c->Linv, M,
                             (const T*)c->Mtmp2, M, &zero, (T*)c->Mtmp3, M));
+        if (refine) {  // R = S - sigma L^T X ; X += (1/sigma) L^-T R
+            const T msigma = (T)(-sigma);
+            HIP_CHECK(c, hipMemcpyAsync(c->Mtmp4, c->Mtmp2, (size_t)M * M * c->esz, hipMemcpyDeviceToDevice, c->stream));
+            BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &msigma, (const T*)c->Lc, M,
+                                (const T*)c->Mtmp3, M, &one, (T*)c->Mtmp4, M));
+            BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &inv_sigma, (const T*)c->Linv, M,
+                                (const T*)c->Mtmp4, M, &one, (T*)c->Mtmp3, M));
+        }
         Tuf = (const T*)c->Mtmp3;
     } else {
         BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, M, &inv_sigma,
@@ -481,11 +502,26 @@ int obj_phase3_impl(cglb_ctx* c, const void* v_full, const double* sc, const voi
         // Guu = L^-T [ (I - B^-1)/2 - (AA^T)/(2 tau) ] L^-1  - c c^T/2
         hipLaunchKernelGGL((mat_combine_kernel<T>), dim3(grid1d_full((int64_t)M * M)), dim3(256), 0, c->stream, (T*)c->Mtmp, M, (T)0.5, (T)-0.5,
                            (const T*)c->Mtmp, (T)(-0.5 / tau), (const T*)c->AAt);
-        if (use_inv) {  // L^-T S L^-1 as two GEMMs
+        if (use_inv) {  // L^-T S L^-1 as two GEMMs (each followed by its refinement step)
+            const size_t mm = (size_t)M * M * c->esz;
             BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one, (const T*)c->Linv, M,
                                 (const T*)c->Mtmp, M, &zero, (T*)c->Mtmp3, M));
+            if (refine) {  // X = L^-T S:  R = S - L^T X ; X += L^-T R
+                HIP_CHECK(c, hipMemcpyAsync(c->Mtmp4, c->Mtmp, mm, hipMemcpyDeviceToDevice, c->stream));
+                BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &minus_one, (const T*)c->Lc, M,
+                                    (const T*)c->Mtmp3, M, &one, (T*)c->Mtmp4, M));
+                BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one, (const T*)c->Linv, M,
+                                    (const T*)c->Mtmp4, M, &one, (T*)c->Mtmp3, M));
+            }
             BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_none, rocblas_operation_none, M, M, M, &one, (const T*)c->Mtmp3, M,
                                 (const T*)c->Linv, M, &zero, (T*)c->Mtmp, M));
+            if (refine) {  // Y = X L^-1:  R = X - Y L ; Y += R L^-1
+                HIP_CHECK(c, hipMemcpyAsync(c->Mtmp4, c->Mtmp3, mm, hipMemcpyDeviceToDevice, c->stream));
+                BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_none, rocblas_operation_none, M, M, M, &minus_one, (const T*)c->Mtmp, M,
+                                    (const T*)c->Lc, M, &one, (T*)c->Mtmp4, M));
+                BLAS_CHECK(c, xgemm(c->blas, rocblas_operation_none, rocblas_operation_none, M, M, M, &one, (const T*)c->Mtmp4, M,
+                                    (const T*)c->Linv, M, &one, (T*)c->Mtmp, M));
+            }
         } else {
             BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, M, M, &one,
                                 (const T*)c->Lc, M, (T*)c->Mtmp, M));
@@ -807,7 +843,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     comm_free(c);
     void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->Xhsq, c->xah, c->wh, c->pwh, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Mtmp3, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
-                    c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk, c->uwh};
+                    c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk, c->uwh, c->Mtmp4};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : c->k1_events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->eval_events) (void)hipEventDestroy(ev);

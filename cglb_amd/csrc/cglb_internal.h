@@ -81,10 +81,11 @@ struct cglb_ctx {
     void* Mtmp = nullptr;    // M x M scratch
     void* Mtmp2 = nullptr;   // M x M scratch
     void* Mtmp3 = nullptr;   // M x M scratch of the gradient algebra (allocated on first use)
+    void* Mtmp4 = nullptr;   // M x M residual scratch of its refinement steps (allocated on first use)
     bool have_Linv = false;  // Linv holds L^-1 of the current K_uu factor
     bool Linv_unchecked = false;  // the trtri status of Linv (info_dev[2]) has not been read back yet
-    int grad_trsm = 2;       // gradient algebra against L: 0 products with the explicit L^-1 (fast), 1 rocBLAS trsm / trsv (backward stable),
-                             // 2 (default) chosen per evaluation: the solves when max diag(L) / min diag(L) > CGLB_LINV_DIAG_RATIO
+    int grad_trsm = 2;       // gradient algebra against L: 0 products with the explicit L^-1 (fastest), 1 rocBLAS trsm / trsv (backward stable),
+                             // 2 (default) the products + one step of iterative refinement against L (accuracy of 1 at ~2/3 of its time)
     double L_diag_ratio = 1.0;  // max diag(L) / min diag(L) of the current K_uu factor (cglb_get_stat "L_diag_ratio")
     void* Guf = nullptr;     // adjoint of Kuf, same layout as At (allocated on first gradient)
     void *fragA = nullptr, *fragB = nullptr;  // MFMA-ordered augmented operands (kernels_kff_mfma.hip)
@@ -142,11 +143,6 @@ struct cglb_ctx {
 };
 
 #define DOTPART_CAP 65536
-// Products with an explicit L^-1 carry a forward error ~ eps cond(L) |L^-1||b|, the triangular solves ~ eps cond(L) |x|; with inducing
-// points on nearly every datum (sweep draw (2024, 186): cond(K_uu) = 3e8, diag ratio 1.1e3) the explicit inverse put the Z gradient 35x
-// above the oracle's own round-off floor, the solves 4.7x (tools/zgrad_owner.py, round 3).  Well-conditioned factors (ratio < ~5 on the
-// synthetic shapes, the headline included) keep the fast products.
-#define CGLB_LINV_DIAG_RATIO 100.0
 
 #define HIP_CHECK(ctx, expr)                                                                         \
     do {                                                                                             \

@@ -243,11 +243,11 @@ int cglb_time_kernel(cglb_ctx* ctx, int which, int reps, double* ms_avg);
  * the context stream) accumulated over the phases of every cglb_objective_and_grad since - common terms | PCG | final mat-vec, preconditioner
  * and bound scalars | gradient - and "eval_count" = the number of evaluations;
  * "comm_allreduce_calls" | "comm_allgather_calls": collectives issued by the library since cglb_comm_init_*;
- * "L_diag_ratio": max/min of diag(chol(K_uu + jitter I)) of the last cglb_setup (option "grad_trsm" = 2 compares it with 100). */
+ * "L_diag_ratio": max/min of diag(chol(K_uu + jitter I)) of the last cglb_setup (a cheap proxy of cond(L)). */
 int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
 /* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" | "sym_order" | "aat_block" | "grad_gram" | "k1_profile" |
  * "grad_trsm" (gradient algebra against L = chol(K_uu): 0 products with the explicit inverse, 1 backward-stable triangular solves, 2 = default:
- *  the solves whenever diag(L) spreads over more than two decades, i.e. K_uu is ill conditioned) |
+ *  the products followed by one step of iterative refinement against L - the accuracy of the solves for about two thirds of their time) |
  * "precision" (1, default: kernel values to <= 1e-13 relative - degree-3 table polynomial, one-step square root; 0: ~3e-16) ...;
  * "final_matvec" (cglb_objective_and_grad after a solve: 1 recomputes K v with a mat-vec like models.py:280; 0, the default, takes K v = e - r
  *  from the residual r the PCG recurrence carries - exact at the start of a solve and after every restart step; measured difference at the

@@ -176,6 +176,9 @@ def test_headline_fixture_from_reference_solver(path, precision):
     assert res.logdet == pytest.approx(float(g["logdet"]), rel=1e-10)
     assert res.bound == pytest.approx(float(g["bound"]), rel=1e-6)                       # north_star
     assert res.lower == pytest.approx(float(g["lower"]), rel=1e-6) and res.upper == pytest.approx(float(g["upper"]), rel=1e-6)
+    if res.steps != ref_steps:   # only possible beyond 40 steps: say so instead of silently checking less
+        import warnings
+        warnings.warn(f"{os.path.basename(path)}: {res.steps} steps against the fixture's {ref_steps}: only the 1e-6 assertions were applied")
     if res.steps == ref_steps:
         # Measured agreement with these fixtures (both precision levels, 15 ... 62 steps): bound <= 3e-14, 1/2 r^T P r <= 5e-11,
         # v <= 2e-11 max|v|, gradient <= 3e-12 of its largest entry (d/d mean, a cancelling sum: 3e-8 of its own value).
@@ -187,8 +190,11 @@ def test_headline_fixture_from_reference_solver(path, precision):
         np.testing.assert_allclose(vs, g["v_sample"], rtol=0, atol=1e-8 * np.abs(g["v_sample"]).max())
         for key in ("lengthscales", "variance", "noise", "mean", "Z"):
             refg = np.asarray(g["g_" + key])
+            # where the fixture carries the oracle's own noise floor of a block (eps-sized moves of Z; ill-conditioned K_uu, e.g. C4's D = 3
+            # at M = 1024), 10x that floor is admissible when it exceeds the fixed tolerance (DESIGN.md section 2 "parity policy")
+            floor = 10.0 * float(g["floor_" + key]) if ("floor_" + key) in g else 0.0
             if key == "mean":
-                np.testing.assert_allclose(np.asarray(res.grad[key]), refg, rtol=1e-5, err_msg=key)
+                np.testing.assert_allclose(np.asarray(res.grad[key]), refg, rtol=1e-5, atol=floor, err_msg=key)
             else:
-                np.testing.assert_allclose(np.asarray(res.grad[key]), refg, rtol=0, atol=1e-9 * np.abs(refg).max(), err_msg=key)
+                np.testing.assert_allclose(np.asarray(res.grad[key]), refg, rtol=0, atol=max(1e-9 * np.abs(refg).max(), floor), err_msg=key)
     ctx.close()

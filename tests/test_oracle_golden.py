@@ -153,3 +153,27 @@ def test_roundoff_sensitivity_tells_stable_from_chaotic_solves():
     w, _ = orc.nystrom_precond(terms.A, terms.LB, hyp.noise, (g["y"] - hyp.mean) - cov @ g["v"])
     floor = orc.grad_roundoff_spread(int(g["kind"]), g["X"], hyp, g["v"], w)
     assert set(floor) == {"lengthscales", "variance", "noise", "mean", "Z"} and all(v >= 0 for v in floor.values())
+
+
+@pytest.mark.parametrize("name", ["rbf_d8_trained", "m32_d3_random", "c1_snelson_like_m32_tight", "rbf_d8_init"])
+def test_objective_is_a_lower_bound_on_the_exact_log_marginal_likelihood(name):
+    """The defining property of the quantity `LowerBoundCG.forward` returns (models.py:151-174; the reference's name for the method):
+    bound <= log N(y | mu, K_ff + sigma^2 I), for any v.  Checked against the dense exact value - independent of how common terms, log-det
+    and bound assembly were restated - and tight when the inducing points sit on every datum and the solve has converged."""
+    g = load_golden(name)
+    hyp = golden_hypers(g)
+    kind, X, y = int(g["kind"]), g["X"], g["y"]
+    N = X.shape[0]
+    cov = orc.dense_cov(kind, X, hyp)
+    err = y - hyp.mean
+    sign, logabsdet = np.linalg.slogdet(cov)
+    exact = -0.5 * float(err @ np.linalg.solve(cov, err)) - 0.5 * logabsdet - 0.5 * N * np.log(2.0 * np.pi)
+    for v0, run_cg, tol in ((g["v0"], True, float(g["max_error"])), (np.zeros(N), False, 1.0), (g["v"], False, 1.0)):
+        ob = orc.objective(kind, X, y, hyp, v0, run_cg, tol)
+        assert ob.bound <= exact + 1e-9 * abs(exact)
+    # inducing points on every datum, converged solve: Q_ff = K_ff (up to the jitter) and the bound closes
+    hyp_full = hyp.copy()
+    hyp_full.Z = X.copy()
+    hyp_full.jitter = 1e-10
+    ob = orc.objective(kind, X, y, hyp_full, np.zeros(N), True, 1e-10)
+    assert ob.bound <= exact + 1e-6 * abs(exact) and ob.bound == pytest.approx(exact, rel=1e-5)

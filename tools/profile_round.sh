@@ -1,10 +1,10 @@
 #!/bin/bash
-# Developer tool (GPU box): the rocprofv3 evidence of a round.  usage: tools/profile_round.sh r02
+# Developer tool (GPU box): the rocprofv3 evidence of a round.  usage: tools/profile_round.sh r03
 #   1. kernel-trace statistics of the benchmark command itself           -> gpurun_out/<tag>_stats/
 #   2. counter passes over tools/pmc_run.py, one --pmc set per pass      -> gpurun_out/<tag>_pmc/   (tools/pmc_collect.sh)
 # Counter passes are never combined with other trace domains; the program after `--` is python3 itself (no launcher hop).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p gpurun_out/${TAG}_stats

@@ -17,7 +17,7 @@ for seed, idx in ((2024, 186), (2024, 187), (2024, 0)):
     dl = np.diag(terms.L)
     print(f"draw {idx}: N={N} D={D} M={M} {kind}  cond(K_uu)~{np.linalg.cond(terms.L)**2:.2e}  max/min diag L = {dl.max()/dl.min():.2e}")
     for prec in (0, 1):
-        for trsm in (0, 1):
+        for trsm in (0, 1, 2):
             ctx = HipContext(X, y, M, kind)
             ctx.set_option("precision", prec); ctx.set_option("grad_trsm", trsm)
             ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
