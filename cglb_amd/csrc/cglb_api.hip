@@ -775,8 +775,7 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     if (!out) { g_create_error = "out is NULL"; return CGLB_ERR_BAD_ARG; }
     *out = nullptr;
     if (d > CGLB_MAX_D) {
-        g_create_error = "input dimension D = " + std::to_string(d) + " exceeds the supported maximum of " + std::to_string(CGLB_MAX_D) +
-                         " (the pair kernels keep a lane's row operands in registers; see INTEGRATION.md)";
+        g_create_error = "input dimension D = " + std::to_string(d) + " exceeds the supported maximum of " + std::to_string(CGLB_MAX_D);
         return CGLB_ERR_BAD_ARG;
     }
     if (n_total <= 0 || row_begin < 0 || row_end < row_begin || row_end > n_total || d <= 0 || m <= 0 ||
@@ -801,7 +800,8 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     CR(dalloc(c, &c->Xs, N * Dp * e)); CR(dalloc(c, &c->xa, N * e)); CR(dalloc(c, &c->Zs, M * Dp * e)); CR(dalloc(c, &c->za, M * e));
     CR(dalloc(c, &c->Zh, M * Dp * e)); CR(dalloc(c, &c->zah, M * e)); CR(dalloc(c, &c->Linv, M * M * e)); CR(dalloc(c, &c->LinvT, M * M * e));
     CR(dalloc(c, &c->w_q, M * e));
-    CR(dalloc(c, &c->Xh, N * Dp * e)); CR(dalloc(c, &c->Xhsq, N * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, &c->wh, N * e)); CR(dalloc(c, &c->pwh, N * e)); CR(dalloc(c, (void**)&c->exp_tab, CGLB_TAB_SIZE * sizeof(double)));
+    const size_t hotN = c->Dp > CGLB_MAX_D_NARROW ? 0 : N;  // the hot operand set exists for the register-resident pair kernels only
+    CR(dalloc(c, &c->Xh, hotN * Dp * e)); CR(dalloc(c, &c->Xhsq, hotN * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, &c->wh, N * e)); CR(dalloc(c, &c->pwh, N * e)); CR(dalloc(c, (void**)&c->exp_tab, CGLB_TAB_SIZE * sizeof(double)));
     {   // 2^x table of the pair kernels: 2^((k + 1/2)/T) for the floor/fract range reduction (devmath.h)
         std::vector<double> tab(CGLB_TAB_SIZE);
         for (int k = 0; k < CGLB_TAB_SIZE; ++k) {
@@ -841,6 +841,7 @@ int cglb_ctx_destroy(cglb_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     comm_free(c);
+    wide_free(c);
     void* ptrs[] = {c->X, c->y, c->Z, c->Xs, c->xa, c->Zs, c->za, c->Xh, c->Xhsq, c->xah, c->wh, c->pwh, c->exp_tab, c->At, c->Lc, c->LBc, c->LBinv, c->LBinvT, c->AAt, c->Mtmp, c->Mtmp2, c->Mtmp3, c->Guf,
                     c->info_dev, c->w_r, c->w_z, c->w_p, c->w_Ap, c->w_Kv, c->w_e, c->w_pfull, c->w_u, c->w_t, c->w_t2, c->kpart, c->tpart,
                     c->dotpart, c->scal, c->gpart, c->gradbuf, c->slabs, c->fragA, c->fragB, c->sym_items, c->Zh, c->zah, c->Linv, c->LinvT, c->w_q, c->ppart, c->chol_blk, c->uwh, c->Mtmp4};
@@ -954,12 +955,16 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
             if (c->m32_bias > CGLB_M32_BIAS_MAX) c->exp_clamp = true;
         }
     }
-    CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
-    CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xh, c->xah, true));
-    CGLB_TRY(launch_hot_weights(c));
-    CGLB_TRY(launch_hot_squares(c));
-    CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zs, c->za));
-    CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zh, c->zah, true));
+    if (is_wide(c)) {  // D > 32: one scaled operand set (+ its squares), Gram products through rocBLAS (kernels_wide.hip)
+        CGLB_TRY(wide_after_hypers(c));
+    } else {
+        CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
+        CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xh, c->xah, true));
+        CGLB_TRY(launch_hot_weights(c));
+        CGLB_TRY(launch_hot_squares(c));
+        CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zs, c->za));
+        CGLB_TRY(launch_prep_scaled(c, c->Z, c->M, c->Zh, c->zah, true));
+    }
     c->frag_valid = false;  // the pre-permuted operands of the experimental matrix-pipe variant are rebuilt on its first use
     c->have_local = c->have_terms = false;
     return CGLB_OK;
@@ -1317,9 +1322,13 @@ static int predict_rows(cglb_ctx* c, const void* v_full, const void* u, const vo
             BLAS_CHECK(c, xtrsv(c->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, M, (const T*)c->LBc, M, (T*)c->w_u, 1));
             hipLaunchKernelGGL((scale2_kernel<T>), dim3(grid1d(M)), dim3(256), 0, c->stream, (const T*)c->w_u, (int64_t)M, inv_sigma, (T*)c->w_u, (T)0, (T*)nullptr);
             // tmp1 = L^-1 Kus (:344), tmp2 = LB^-1 tmp1 (:345); panels stored [M][ld] row-major == (ld x M) column-major
-            dim3 grid((unsigned)((n_new + 255) / 256), (unsigned)((M + 31) / 32));
-            CGLB_DISPATCH_KIND(c->kind, CGLB_DISPATCH_DP(c->Dp, hipLaunchKernelGGL((kus_kernel<T, KIND, DP>), grid, dim3(256), 0, c->stream, (const T*)c->Zs,
-                                                                                    (const T*)xs, n_new, ld, M, (T)c->var, (T*)t1)));
+            if (is_wide(c)) {
+                CGLB_TRY(wide_kus(c, xs, xa, n_new, ld, t1));
+            } else {
+                dim3 grid((unsigned)((n_new + 255) / 256), (unsigned)((M + 31) / 32));
+                CGLB_DISPATCH_KIND(c->kind, CGLB_DISPATCH_DP(c->Dp, hipLaunchKernelGGL((kus_kernel<T, KIND, DP>), grid, dim3(256), 0, c->stream, (const T*)c->Zs,
+                                                                                        (const T*)xs, n_new, ld, M, (T)c->var, (T*)t1)));
+            }
             BLAS_CHECK(c, xtrsm(c->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, (int)n_new, M, &one,
                                 (const T*)c->Lc, M, (T*)t1, (int)ld));
             HIP_CHECK(c, hipMemcpyAsync(t2, t1, (size_t)M * ld * c->esz, hipMemcpyDeviceToDevice, c->stream));

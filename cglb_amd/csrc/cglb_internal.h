@@ -11,7 +11,8 @@
 
 #include "../../include/cglb_hip.h"
 
-#define CGLB_MAX_D 32
+#define CGLB_MAX_D 1024        // widest input the context accepts (host-side arrays)
+#define CGLB_MAX_D_NARROW 32   // widest input of the register-resident pair kernels; beyond it the "wide" path runs (kernels_wide.hip)
 #define CGLB_WAVE 64
 
 // Collectives of the N-rank path inside the library (cglb_comm_init_*, cglb_dist_*; include/cglb_hip.h): RCCL on the context stream, or
@@ -67,6 +68,12 @@ struct cglb_ctx {
     int precond_mode = 0;                // 0: stored panel A (reference form), 1: implicit K_uf products
     void *Xhsq = nullptr;  // Xh squared element-wise: second-moment operand of the Gram-form gradient pass (kernels_grad.hip)
     const void* pwh_src = nullptr;       // vector whose weighted copy pwh currently holds (set by update_p, consumed once by the next symmetric mat-vec)
+    // wide inputs (D > 32, kernels_wide.hip): element-wise squares of the scaled operands, tile / panel / moment scratch, device copies of
+    // the per-dimension centre and scale
+    void *Xsq = nullptr, *Zsq = nullptr;
+    void *wtile = nullptr, *wpart = nullptr, *wS1 = nullptr, *wVX = nullptr, *wR = nullptr, *wC = nullptr, *wones = nullptr, *wpanel = nullptr;
+    size_t wtile_cap = 0, wpart_cap = 0, wS1_cap = 0, wpanel_cap = 0, wvec_cap = 0;
+    double *wcenter = nullptr, *wscale = nullptr, *wsmall = nullptr;
     void* uwh = nullptr;                 // u o wh: second weighted column operand of the Gram-form gradient pass (allocated on first use)
     void *wh = nullptr, *pwh = nullptr;  // RBF column weights 2^(xah_j/T) and the weighted operand p_j * wh_j of the symmetric mat-vec (length N)
     void *Xh = nullptr, *xah = nullptr;  // hot operand set of the pair kernels: exponents in 1/T octave, T = 2^CGLB_TAB_BITS (devmath.h exp2_tab)
@@ -177,8 +184,25 @@ static inline int pad_dim(int d) {
     const int sizes[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 28, 32};  // 10, 20 and 28: the reference's own data sets have D = 9, 17, 18, 26, 27
     for (int s : sizes)
         if (d <= s) return s;
-    return -1;
+    return d;  // wide inputs are not padded: their Gram products go through rocBLAS (kernels_wide.hip)
 }
+static inline bool is_wide(const cglb_ctx* c);
+
+static inline bool is_wide(const cglb_ctx* c) { return c->Dp > CGLB_MAX_D_NARROW; }
+
+// kernels_wide.hip: D > 32.  The Gram part of the pair value is a contraction with k = D and goes through rocBLAS in tiles; same
+// contracts as the launchers below they stand in for.
+int wide_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out, void* Xsq_out);
+int wide_after_hypers(cglb_ctx* c);
+int wide_kuf(cglb_ctx* c);
+int wide_kuu(cglb_ctx* c);
+int wide_kus(cglb_ctx* c, const void* XsNew, const void* xaNew, int64_t n_new, int64_t ld, void* out);
+int wide_matvec(cglb_ctx* c, const void* XsRow, const void* xaRow, int64_t row0_global, int64_t nrows, const void* p_full, void* out, bool diag_noise,
+                double* pdot_slot, int tile_stride, int tile_offset);
+int wide_grad_kff(cglb_ctx* c, const void* v_full, const void* u_rows, int64_t row0, int64_t nrows, int tile_stride, int tile_offset, double* out_dl);
+int wide_grad_panel(cglb_ctx* c, const void* G, int64_t ldg, const void* cvec, const void* wvec, const void* XsCol, const void* xaCol, const void* XsqCol,
+                    int64_t ncols, double zfactor, double* out);
+void wide_free(cglb_ctx* c);
 
 // ---- launchers implemented in the kernel translation units (all enqueue on ctx->stream) ----------
 // kernels_prep.hip

@@ -50,6 +50,6 @@
     } while (0)
 
 struct ScaleParams {
-    double center[CGLB_MAX_D];
-    double scale[CGLB_MAX_D];  // kscale / l_d
+    double center[CGLB_MAX_D_NARROW];
+    double scale[CGLB_MAX_D_NARROW];  // kscale / l_d
 };

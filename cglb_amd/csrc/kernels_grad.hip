@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void square_kernel(const T* __restrict__ x, in
 }
 // Xhsq = Xh .* Xh (after set_hypers): the second-moment operand of the Gram-form gradient pass
 int launch_hot_squares(cglb_ctx* c) {
+    if (is_wide(c)) return CGLB_OK;
     const int64_t tot = c->N * c->Dp;
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((square_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, (const T*)c->Xh,
                                                  tot, (T*)c->Xhsq));
@@ -295,9 +296,10 @@ static int grad_fold_operands(cglb_ctx* c, const void* v_full, const void* u, in
 
 // out_dl[d] (device double[D], overwritten) = sum_{i local, j} u_i dK_ij/dl_d v_j
 int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double* out_dl) {
+    if (is_wide(c)) return wide_grad_kff(c, v_full, u_local, c->r0, c->nloc, 1, 0, out_dl);
     ScaleParams sp;
     const double ks = kscale_of(c) * cglb_hot_scale(c);  // the N^2 pass runs on the hot operand set
-    for (int d = 0; d < CGLB_MAX_D; ++d) {
+    for (int d = 0; d < CGLB_MAX_D_NARROW; ++d) {
         sp.center[d] = 0;
         sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
     }
@@ -366,9 +368,10 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
 // Cyclic form for the multi-GPU path: the whole N x N form in its symmetric version, row blocks rb == par_rank (mod par_world).
 // u_full, v_full: all N entries.  out_dl (device double[D], overwritten) is this rank's PARTIAL sum (all-reduced by the caller).
 int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, double* out_dl) {
+    if (is_wide(c)) return wide_grad_kff(c, v_full, u_full, 0, c->N, c->par_world, c->par_rank, out_dl);
     ScaleParams sp;
     const double ks = kscale_of(c) * cglb_hot_scale(c);
-    for (int d = 0; d < CGLB_MAX_D; ++d) {
+    for (int d = 0; d < CGLB_MAX_D_NARROW; ++d) {
         sp.center[d] = 0;
         sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
     }
@@ -503,7 +506,7 @@ static int grad_panel(cglb_ctx* c, const void* G, int64_t ldg, const void* cvec,
     if (ncols == 0) return CGLB_OK;
     ScaleParams sp;
     const double ks = kscale_of(c);
-    for (int d = 0; d < CGLB_MAX_D; ++d) {
+    for (int d = 0; d < CGLB_MAX_D_NARROW; ++d) {
         sp.scale[d] = d < c->D ? 1.0 / (c->ls[d] * ks * ks) : 0.0;
         sp.center[d] = d < c->D ? 1.0 / (c->ls[d] * ks) : 0.0;
     }
@@ -526,11 +529,15 @@ static int grad_panel(cglb_ctx* c, const void* G, int64_t ldg, const void* cvec,
 
 // Kuf part: adjoint = c->Guf (+ cvec[m] * w_local[n]); columns = local rows of X.
 int launch_grad_kuf(cglb_ctx* c, const void* cvec, const void* w_local, double* out) {
+    if (is_wide(c))
+        return wide_grad_panel(c, c->Guf, c->lda, cvec, w_local, (const char*)c->Xs + (size_t)c->r0 * c->Dp * c->esz, (const char*)c->xa + (size_t)c->r0 * c->esz,
+                               (const char*)c->Xsq + (size_t)c->r0 * c->Dp * c->esz, c->nloc, 1.0, out);
     return grad_panel(c, c->Guf, c->lda, cvec, w_local, (const char*)c->Xs + (size_t)c->r0 * c->Dp * c->esz, c->nloc, 1.0, out);
 }
 
 // Kuu part: adjoint = Guu (symmetric M x M) - c c^T/2 passed as rank-1 (cvec, wvec = -c/2); columns = Z.
 // z_m appears in row and column of K_uu, hence the factor 2 on dZ.
 int launch_grad_kuu(cglb_ctx* c, const void* Guu, const void* cvec, const void* mhalf_c, double* out) {
+    if (is_wide(c)) return wide_grad_panel(c, Guu, c->M, cvec, mhalf_c, c->Zs, c->za, c->Zsq, c->M, 2.0, out);
     return grad_panel(c, Guu, c->M, cvec, mhalf_c, c->Zs, c->M, 2.0, out);
 }

@@ -321,6 +321,7 @@ static int kff_rect_generic(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t
 int launch_pairs_rect(cglb_ctx* c, const void* XsRow, const void* xaRow, int64_t nrows, const void* XsCol, const void* xaCol, const void* pcol,
                       int64_t col0, int64_t col1, void* out) {
     if (nrows == 0) return CGLB_OK;
+    if (is_wide(c)) return cglb_fail(c, CGLB_ERR_STATE, "the implicit preconditioner (precond_mode 1) is not available for inputs wider than 32 dimensions");
     if (col1 <= col0) {
         HIP_CHECK(c, hipMemsetAsync(out, 0, (size_t)nrows * c->esz, c->stream));
         return CGLB_OK;
@@ -341,6 +342,9 @@ int launch_kff_plain_range(cglb_ctx* c, const void* p_full, int64_t col0, int64_
 // out_local = K_ff[rows,:] p + noise p[rows]; if pdot_slot != null also sum_i p_i out_i over local rows.
 int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot) {
     if (c->nloc == 0) return CGLB_OK;
+    if (is_wide(c))
+        return wide_matvec(c, (const char*)c->Xs + (size_t)c->r0 * c->Dp * c->esz, (const char*)c->xa + (size_t)c->r0 * c->esz, c->r0, c->nloc, p_full, out_local, true,
+                           pdot_slot, 1, 0);
     if (c->kff_variant == 2) return launch_kff_sym(c, p_full, out_local, pdot_slot);  // symmetric form (kernels_kff_sym.hip)
     if (c->kff_variant == 1 && c->dtype == CGLB_F64 && (c->r0 & 15) == 0) {  // matrix-pipe Gram path (kernels_kff_mfma.hip)
         int64_t jsplit = 1;
@@ -355,6 +359,7 @@ int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* 
 
 // out[i] = var * sum_j kappa(xnew_i, x_j) v_j over all N columns (no diagonal term).
 int launch_cross_matvec(cglb_ctx* c, const void* Xs_new, const void* xa_new, int64_t n_new, const void* v_full, void* out) {
+    if (is_wide(c)) return wide_matvec(c, Xs_new, xa_new, 0, n_new, v_full, out, false, nullptr, 1, 0);
     // new points may lie far outside the training range: always take the range-clamped 2^x here
     const bool saved = c->exp_clamp;
     c->exp_clamp = true;

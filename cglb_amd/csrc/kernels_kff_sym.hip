@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void weight_operand_kernel(const T* __restrict
     if (i < n) pw[i] = p[i] * wh[i];
 }
 int launch_hot_weights(cglb_ctx* c) {
-    if (c->kind != CGLB_RBF) return CGLB_OK;
+    if (c->kind != CGLB_RBF || is_wide(c)) return CGLB_OK;
     const int grid = (int)((c->N + 255) / 256);
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((hot_weights_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->xah, c->N, (T*)c->wh));
     CGLB_LAUNCH_CHECK(c);
@@ -614,11 +614,14 @@ int k1_profile_collect(cglb_ctx* c) {
 }
 
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot) {
+    if (is_wide(c)) return launch_kff_matvec(c, p_full, out_local, pdot_slot);
     CGLB_DISPATCH_ALL(c, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out_local, pdot_slot, false)));
     return CGLB_OK;
 }
 
 int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial) {
+    // wide inputs: row tiles of the full square dealt round-robin to the ranks; every rank adds the noise term on its own rows
+    if (is_wide(c)) return wide_matvec(c, c->Xs, c->xa, 0, c->N, p_full, out_full_partial, true, nullptr, c->par_world, c->par_rank);
     CGLB_DISPATCH_ALL(c, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out_full_partial, nullptr, true)));
     return CGLB_OK;
 }

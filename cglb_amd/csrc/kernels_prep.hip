@@ -25,10 +25,11 @@ __global__ __launch_bounds__(256) void prep_scaled_kernel(const T* __restrict__ 
 double cglb_hot_scale(const cglb_ctx* c) { return (c->kind == CGLB_RBF) ? sqrt(CGLB_HOT_UNITS) : 0.5 * CGLB_HOT_UNITS; }
 
 int launch_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out, bool hot) {
+    if (is_wide(c)) return wide_prep_scaled(c, Xraw, n, Xs_out, xa_out, nullptr);  // one operand set: the wide path has no "hot" units
     ScaleParams sp;
     double kscale = (c->kind == CGLB_RBF) ? sqrt(CGLB_LOG2E) : CGLB_SQRT3 * CGLB_LOG2E;
     if (hot) kscale *= cglb_hot_scale(c);
-    for (int d = 0; d < CGLB_MAX_D; ++d) {
+    for (int d = 0; d < CGLB_MAX_D_NARROW; ++d) {
         sp.center[d] = d < c->D ? c->xmean[d] : 0.0;
         sp.scale[d] = d < c->D ? kscale / c->ls[d] : 0.0;
     }
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256) void kuf_kernel(const T* __restrict__ Zs, cons
 
 int launch_kuf(cglb_ctx* c) {
     if (c->nloc == 0) return CGLB_OK;
+    if (is_wide(c)) return wide_kuf(c);
     const int mchunk = 32;
     dim3 grid((unsigned)((c->nloc + 255) / 256), (unsigned)((c->M + mchunk - 1) / mchunk));
     CGLB_DISPATCH_ALL(c, hipLaunchKernelGGL((kuf_kernel<T, KIND, DP>), grid, dim3(256), 0, c->stream, (const T*)c->Zs,
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256) void kuu_kernel(const T* __restrict__ Zs, int 
 }
 
 int launch_kuu(cglb_ctx* c) {
+    if (is_wide(c)) return wide_kuu(c);
     const int64_t tot = (int64_t)c->M * c->M;
     const int grid = (int)((tot + 255) / 256);
     CGLB_DISPATCH_ALL(c, hipLaunchKernelGGL((kuu_kernel<T, KIND, DP>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->Zs,

@@ -17,7 +17,7 @@ struct SelPivot {
 template <typename T, int KIND, int DP>
 __global__ __launch_bounds__(256) void select_step_kernel(const T* __restrict__ Xs, int64_t n, T* __restrict__ C, int m, T* __restrict__ d,
                                                           const SelPivot* __restrict__ piv, const T* __restrict__ cjv, T var, T jitter,
-                                                          T* __restrict__ pval, long long* __restrict__ pidx) {
+                                                          T* __restrict__ pval, long long* __restrict__ pidx, int Dw) {
     __shared__ T sval[4];
     __shared__ long long sidx[4];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -27,10 +27,17 @@ __global__ __launch_bounds__(256) void select_step_kernel(const T* __restrict__ 
     long long bidx = 0x7fffffffffffffffLL;
     if (i < n) {
         T d2 = 0;
+        if constexpr (DP == 0) {  // wide inputs: run-time width (rows are read sequentially: whole cache lines are used)
+            for (int q = 0; q < Dw; ++q) {
+                const T df = Xs[i * Dw + q] - Xs[j * Dw + q];
+                d2 = tfma<T>(df, df, d2);
+            }
+        } else {
 #pragma unroll
-        for (int q = 0; q < DP; ++q) {
-            const T df = Xs[i * DP + q] - Xs[j * DP + q];
-            d2 = tfma<T>(df, df, d2);
+            for (int q = 0; q < DP; ++q) {
+                const T df = Xs[i * DP + q] - Xs[j * DP + q];
+                d2 = tfma<T>(df, df, d2);
+            }
         }
         T col = var * kappa_from_d2<T, KIND>(d2);
         if (i == j) col += jitter;
@@ -162,7 +169,7 @@ static int select_impl(cglb_ctx* c, double variance, double jitter, long long* c
                        0, piv, cjv, chosen_dev, 0);
     for (int m = 0; m < M; ++m) {  // the step of the last pivot only serves the reported trace (all M points conditioned on)
         hipLaunchKernelGGL((select_step_kernel<T, KIND, DP>), dim3(nparts), dim3(256), 0, c->stream, (const T*)c->Xs, n, C, m, d,
-                           (const SelPivot*)piv, (const T*)cjv, (T)variance, (T)jitter, pval, pidx);
+                           (const SelPivot*)piv, (const T*)cjv, (T)variance, (T)jitter, pval, pidx, c->D);
         if (m + 1 < M)
             hipLaunchKernelGGL((select_pivot_kernel<T>), dim3(1), dim3(256), 0, c->stream, (const T*)pval, (const long long*)pidx, nparts,
                                (const T*)C, n, m + 1, piv, cjv, chosen_dev, m + 1);
@@ -179,6 +186,7 @@ static int select_impl(cglb_ctx* c, double variance, double jitter, long long* c
 }
 
 int launch_select_inducing(cglb_ctx* c, double variance, double jitter, long long* chosen_dev, void* Z_out, double* trace_dev) {
+    if (is_wide(c)) { CGLB_DISPATCH_T(c->dtype, CGLB_DISPATCH_KIND(c->kind, return (select_impl<T, KIND, 0>(c, variance, jitter, chosen_dev, Z_out, trace_dev)))); }
     CGLB_DISPATCH_ALL(c, return (select_impl<T, KIND, DP>(c, variance, jitter, chosen_dev, Z_out, trace_dev)));
     return CGLB_OK;
 }

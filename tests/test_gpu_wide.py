@@ -1,0 +1,138 @@
+"""Inputs wider than 32 dimensions (the reference accepts any Wilson UCI set, datasets.py:47-76: buzz 77, song 90, slice 385 ...): the
+Gram part of the pair value goes through rocBLAS in tiles (cglb_amd/csrc/kernels_wide.hip).  Every seam against the dense oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import cglb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(N, D, M, seed, ell_factor=1.0):
+    X, y, Z = orc.synthetic_problem(N, D, M, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    ls = rng.uniform(0.8, 1.6, size=D) * np.sqrt(D) * ell_factor       # lengthscales ~ sqrt(D): correlated over the data range
+    return X, y, Z, orc.Hypers(ls, 1.3, 0.08, 0.15, Z, 1e-6)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+@pytest.mark.parametrize("N,D,M", [(700, 33, 24), (1500, 77, 48), (600, 385, 32)])
+def test_wide_inputs_every_seam_against_the_oracle(kind, N, D, M):
+    from cglb_amd.hip_context import HipContext
+    X, y, Z, hyp = _problem(N, D, M, seed=D)
+    ctx = HipContext(X, y, M, kind)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+    ctx.setup()
+    cov = orc.dense_cov(kind, X, hyp)
+    terms = orc.common_terms(kind, X, hyp)
+    # operator and preconditioner seams
+    p = np.random.default_rng(1).standard_normal(N)
+    Ap = ctx.matvec(torch.from_numpy(p)).cpu().numpy()
+    np.testing.assert_allclose(Ap, cov @ p, rtol=0, atol=1e-11 * np.abs(cov @ p).max())
+    np.testing.assert_allclose(ctx.get_matrix("A").cpu().numpy(), terms.A, rtol=0, atol=1e-9 * np.abs(terms.A).max())
+    np.testing.assert_allclose(ctx.get_matrix("LB").cpu().numpy(), terms.LB, rtol=0, atol=1e-9 * np.abs(terms.LB).max())
+    z, rz = ctx.precond(p)
+    zr, rzr = orc.nystrom_precond(terms.A, terms.LB, hyp.noise, p)
+    np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=0, atol=1e-10 * np.abs(zr).max())
+    # evaluation: solve, bound, gradient
+    v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
+    res = ctx.objective_and_grad(v, True, 1e-2, 100, 40)
+    ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, 1e-2, 100, 40, cov=cov)
+    assert abs(res.steps - ref.steps) <= (0 if ref.steps <= 40 else 1)
+    refg = orc.objective(kind, X, y, hyp, v.cpu().numpy(), run_cg=False, with_grad=True, cov=cov)
+    assert res.bound == pytest.approx(refg.bound, rel=1e-10)
+    if res.steps == ref.steps and res.steps <= 40:
+        assert res.bound == pytest.approx(ref.bound, rel=1e-8)
+    for key in ("lengthscales", "Z", "variance", "noise", "mean"):
+        a, b = np.asarray(res.grad[key]), np.asarray(refg.grad[key])
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-7 * max(np.abs(b).max(), 1e-3 * abs(ref.bound)), err_msg=key)
+    # prediction and cross mat-vec (new points far outside the data as well)
+    xnew = np.random.default_rng(2).standard_normal((57, D)) * np.linspace(0.5, 3.0, 57)[:, None]
+    ctx.setup()
+    pm, pv = ctx.predict(v, xnew)
+    om, ov, _, _ = orc.predict(kind, X, y, hyp, v.cpu().numpy(), xnew, max_error=1e300)
+    np.testing.assert_allclose(pm.cpu().numpy(), om, rtol=0, atol=1e-9 * np.abs(om).max())
+    np.testing.assert_allclose(pv.cpu().numpy(), ov, rtol=0, atol=1e-9 * np.abs(ov).max())
+    cm = ctx.cross_matvec(xnew, torch.from_numpy(p)).cpu().numpy()
+    np.testing.assert_allclose(cm, orc.kernel_matrix(kind, xnew, X, hyp.lengthscales, hyp.variance) @ p, rtol=0, atol=1e-11 * np.abs(cm).max())
+    ctx.close()
+
+
+def test_wide_inducing_point_selection_and_backend_training_step():
+    """Greedy conditional-variance selection and three L-BFGS-B iterations through the backend mirror at D = 50."""
+    from cglb_amd.backend import BACKENDS, CGLBConfig, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS
+    from cglb_amd.backend.callbacks import Logger
+    from cglb_amd.backend.interface import _InitKernel
+    from oracle.cglb_oracle import greedy_conditional_variance
+    N, D, M = 900, 50, 20
+    X, y, _ = orc.synthetic_problem(N, D, M, seed=9)
+    be = BACKENDS["hip"]
+    be.configure_backend(logdir="/tmp/cglb_amd_test", keops=False)
+    be.set_default_float("fp64")
+    be.set_default_jitter("fp64")
+    model = be.create_model(CGLBConfig(kernel=KERNEL_CONFIGS["Matern32"](), inducing_variable=INDUCING_VARIABLE_CONFIGS["cv"](M)), (X, y))
+    Zsel = be.model_parameters(model)[".inducing_variable.Z"]
+    np.testing.assert_array_equal(Zsel, greedy_conditional_variance(X, M, _InitKernel(model.covar_module.base_kernel).__call__))
+    logger = Logger("/tmp/cglb_amd_test", lambda: {}, lambda: be.model_parameters(model), holdout_interval=-1, verbose=False)
+    from cglb_amd.backend.models import LowerBoundCG
+    with torch.no_grad():
+        l0 = float(-LowerBoundCG(model)(None))
+    results = be.optimize(model, ((X, y), (X[:5], y[:5])), 3, logger, "scipy")
+    assert sum(r.nit for r in results) == 3 and np.isfinite(results[-1].fun) and results[-1].fun < l0
+    model.hip.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dist_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cglb_amd.dist_context import DistHipContext
+        N, D, M = 9000, 40, 32       # three 4096-row tiles: dealt 2 + 1 over the two ranks
+        X, y, Z, hyp = _problem(N, D, M, seed=3)
+        ctx = DistHipContext(X, y, M, "rbf", collectives="callbacks")
+        ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+        v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
+        r = ctx.objective_and_grad(v, True, 1.0, 100, 40)
+        q.put((rank, r.steps, r.bound, v.cpu().numpy(), r.grad))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_wide_inputs_on_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    N, D, M = 9000, 40, 32
+    X, y, Z, hyp = _problem(N, D, M, seed=3)
+    cov = orc.dense_cov("rbf", X, hyp)
+    ref = orc.objective("rbf", X, y, hyp, np.zeros(N), True, 1.0, 100, 40, cov=cov)
+    for rank, steps, bound, v, grad in out:
+        assert abs(steps - ref.steps) <= (0 if ref.steps <= 40 else 1), rank      # 60 steps: beyond the first restart
+        refg = orc.objective("rbf", X, y, hyp, v, run_cg=False, with_grad=True, cov=cov)
+        assert bound == pytest.approx(refg.bound, rel=1e-10)
+        np.testing.assert_allclose(grad["lengthscales"], refg.grad["lengthscales"], rtol=0, atol=1e-7 * np.abs(refg.grad["lengthscales"]).max())
+        np.testing.assert_allclose(grad["Z"], refg.grad["Z"], rtol=0, atol=1e-7 * np.abs(refg.grad["Z"]).max())
+    assert out[0][1:3] == out[1][1:3]
