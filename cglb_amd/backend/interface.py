@@ -259,7 +259,7 @@ def _assert_ranks_agree(model: CGLB, what: str):
     """N ranks each run the reference's single-process optimiser on what must be identical (loss, gradient) sequences: the loss of the
     last evaluation and a checksum of the parameters are all-gathered once per round; a rank that drifted raises on EVERY rank (all
     see the same gathered numbers), instead of the job running on with replicas that no longer describe one model."""
-    ctx = model.hip
+    ctx = getattr(model, "hip", None)
     if getattr(ctx, "world", 1) <= 1:
         return
     import torch.distributed as dist

@@ -324,6 +324,10 @@ int require_single(cglb_ctx* c) {
     return CGLB_OK;
 }
 
+// look-ahead threshold: speculate on the next mat-vec while 1/2 r^T P r of the PREVIOUS iteration exceeds factor x max_error
+// (option "pcg_lookahead": 0 off, 1 the default factor, k >= 2 that factor)
+inline double lookahead_factor(const cglb_ctx* c) { return c->pcg_lookahead >= 2 ? (double)c->pcg_lookahead : CGLB_LOOKAHEAD_FACTOR; }
+
 // ---- PCG (conjugate_gradient.py:41-86) ----------------------------------------------------------------------
 int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter, int restart_iter, int* steps, double* half_rz) {
     double* S = c->scal;
@@ -348,7 +352,7 @@ int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter
     double rz = 0;
     CGLB_TRY(read_scalars(c, s_rz, &rz, 1));
     // The stop predicate (:65) is evaluated on the host, like the reference's (:80-81).  Look-ahead: while the residual is
-    // still far above the tolerance (more than 4x after the PREVIOUS iteration), the mat-vec of the next iteration is enqueued
+    // still far above the tolerance (more than CGLB_LOOKAHEAD_FACTOR = 32x after the PREVIOUS iteration), the mat-vec of the next iteration is enqueued
     // before the host waits for this iteration's scalar, so the GPU does not idle over the read-back.  If the predicate then
     // says stop, that mat-vec was wasted (it only writes Ap and the p.Ap slot): results are identical either way.
     int i = 0;
@@ -366,7 +370,7 @@ int pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max_iter
         std::swap(s_rz, s_nrz);                                                                     // :76
         HIP_CHECK(c, hipMemcpyAsync(c->host_scal, s_rz, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(c, hipEventRecord(c->scal_event, c->stream));
-        ahead = c->pcg_lookahead && (i + 1 < max_iter) && (0.5 * rz > 4.0 * max_error);  // rz: still the value of the previous iteration
+        ahead = c->pcg_lookahead && (i + 1 < max_iter) && (0.5 * rz > lookahead_factor(c) * max_error);  // rz: still the value of the previous iteration
         if (ahead) CGLB_TRY(launch_kff_matvec(c, c->w_p, c->w_Ap, S + S_PAP));
         HIP_CHECK(c, hipEventSynchronize(c->scal_event));                                            // host test of :65 (and the sync of :80-81)
         rz = c->host_scal[0];
@@ -739,7 +743,7 @@ int dist_pcg_impl(cglb_ctx* c, const void* b, void* v, double max_error, int max
         std::swap(s_rz, s_nrz);                                                                    // :76
         HIP_CHECK(c, hipMemcpyAsync(c->host_scal, s_rz, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(c, hipEventRecord(c->scal_event, c->stream));
-        ahead = c->pcg_lookahead && (i + 1 < max_iter) && (0.5 * rz > 4.0 * max_error);
+        ahead = c->pcg_lookahead && (i + 1 < max_iter) && (0.5 * rz > lookahead_factor(c) * max_error);
         if (ahead) CGLB_TRY(dist_matvec(c, m->p, m->Ap));                                          // kernel + all-reduce enqueued before the host waits
         HIP_CHECK(c, hipEventSynchronize(c->scal_event));
         rz = c->host_scal[0];  // a function of all-gathered numbers only: every rank reads the same value and leaves the loop together

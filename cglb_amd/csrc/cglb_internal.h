@@ -150,6 +150,12 @@ struct cglb_ctx {
 };
 
 #define DOTPART_CAP 65536
+// A mis-speculated mat-vec costs 2.9 ms at the headline shape, the stall it avoids 38 us: speculation must be right ~99 % of the time.
+// Measured on 33 warm-started training evaluations (tools/lookahead_waste.py, profiles/r03_lookahead_waste.log): factor 4 wasted 16
+// mat-vecs (median evaluation 32.1 ms), 16 one, 64 none (29.05 ms).
+#ifndef CGLB_LOOKAHEAD_FACTOR
+#define CGLB_LOOKAHEAD_FACTOR 32.0
+#endif
 
 #define HIP_CHECK(ctx, expr)                                                                         \
     do {                                                                                             \

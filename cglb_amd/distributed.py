@@ -455,7 +455,7 @@ class SymShardedCGLB:
             # tolerance the next mat-vec (kernel + all-reduce) is enqueued before the host waits for this iteration's scalar;
             # if the test then says stop it was wasted work on Ap only.  rz comes from gathered partials -> same decision everywhere.
             pending = self._read_scalar_async(self.rz)
-            ahead = self.lookahead and (i + 1 < max_cg_iter) and (0.5 * rz > 4.0 * max_error)
+            ahead = self.lookahead and (i + 1 < max_cg_iter) and (0.5 * rz > 32.0 * max_error)   # same factor as the library (CGLB_LOOKAHEAD_FACTOR)
             if ahead:
                 self.matvec(self.p, self.Ap)
             rz = pending()

@@ -249,6 +249,8 @@ int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
  * "grad_trsm" (gradient algebra against L = chol(K_uu): 0 products with the explicit inverse, 1 backward-stable triangular solves, 2 = default:
  *  the products followed by one step of iterative refinement against L - the accuracy of the solves for about two thirds of their time) |
  * "precision" (1, default: kernel values to <= 1e-13 relative - degree-3 table polynomial, one-step square root; 0: ~3e-16) ...;
+ * "pcg_lookahead" (0: the host waits for the stop statistic before enqueuing anything; 1, default: the next mat-vec is enqueued first while
+ *  1/2 r^T P r of the previous iteration exceeds 32 x max_error; k >= 2: that factor - a mis-speculated mat-vec is wasted work, never a wrong result) |
  * "final_matvec" (cglb_objective_and_grad after a solve: 1 recomputes K v with a mat-vec like models.py:280; 0, the default, takes K v = e - r
  *  from the residual r the PCG recurrence carries - exact at the start of a solve and after every restart step; measured difference at the
  *  headline shape: bound <= 3e-15 relative, gradient <= 1e-10 of its largest entry, one N^2 pass saved per evaluation) |
