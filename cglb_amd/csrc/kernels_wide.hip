@@ -117,6 +117,31 @@ __global__ __launch_bounds__(256) void wide_rowsum_reduce_kernel(const T* __rest
     out[i] = o;
 }
 
+// Symmetric use of a Gram tile that lies right of the diagonal: kappa_ij serves out_i += kappa p_j (row sums, as above) AND
+// out_j += kappa p_i (column sums: a wave reduction per column, 12 shuffle/add per 64 pairs).  pcpart[(bx * 4 + wave)][j].
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void wide_rowcol_kernel(const T* __restrict__ G, int64_t ld, int64_t nr, int64_t nc, const T* __restrict__ arow,
+                                                          const T* __restrict__ acol, const T* __restrict__ prow, const T* __restrict__ pcol,
+                                                          T* __restrict__ part, T* __restrict__ pcpart) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j0 = (int64_t)blockIdx.y * CSLICE;
+    const int64_t j1 = j0 + CSLICE < nc ? j0 + CSLICE : nc;
+    const bool live = i < nr;
+    const int64_t ii = live ? i : nr - 1;
+    const T ai = arow[ii];
+    const T pi = live ? prow[ii] : T(0);
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    T acc = 0;
+    for (int64_t j = j0; j < j1; ++j) {
+        const T k = live ? wide_profile<T, KIND, 0>(G[ii + j * ld], ai, acol[j]) : T(0);
+        acc = tfma<T>(k, pcol[j], acc);
+        const T cs = wave_sum(k * pi);
+        if (lane == 0) pcpart[chunk * nc + j] = cs;
+    }
+    if (live) part[(int64_t)blockIdx.y * nr + i] = acc;
+}
+
 template <typename T> __global__ __launch_bounds__(256) void wide_fill_kernel(T* __restrict__ x, int64_t n, T v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = v;
@@ -249,24 +274,43 @@ int matvec_impl(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t row0_global
                 double* pdot_slot, int tile_stride, int tile_offset) {
     const int64_t N = c->N;
     CGLB_TRY(wensure(c, &c->wtile, &c->wtile_cap, (size_t)TILE * TILE * sizeof(T)));
-    CGLB_TRY(wensure(c, &c->wpart, &c->wpart_cap, (size_t)(TILE / CSLICE) * TILE * sizeof(T)));
+    // [row-sum partials: (TILE / CSLICE) x TILE | column-sum partials: (TILE / 64) x TILE]
+    CGLB_TRY(wensure(c, &c->wpart, &c->wpart_cap, (size_t)2 * (TILE / CSLICE) * TILE * sizeof(T)));
     T* G = (T*)c->wtile;
+    T* part = (T*)c->wpart;
+    T* pcpart = part + (size_t)(TILE / CSLICE) * TILE;
+    // The square of the training inputs (all rows against all columns: the single-GPU mat-vec and the cyclic multi-GPU form) is evaluated
+    // on its upper block triangle only, every tile right of the diagonal serving its transposed contribution as well: half the Gram GEMMs
+    // and half the kernel evaluations.  Rectangular products (new points, a row shard) take every tile.
+    const bool sym = (XsRow == (const T*)c->Xs) && row0_global == 0 && nrows == N;
+    if (sym) HIP_CHECK(c, hipMemsetAsync(out, 0, (size_t)N * sizeof(T), c->stream));
     int64_t t = 0;
     for (int64_t i0 = 0; i0 < nrows; i0 += TILE, ++t) {
         const int64_t nr = std::min(TILE, nrows - i0);
-        if (tile_stride > 1 && (t % tile_stride) != tile_offset) {  // another rank's row tile: its rows of this partial stay zero
-            HIP_CHECK(c, hipMemsetAsync(out + i0, 0, (size_t)nr * sizeof(T), c->stream));
+        const bool mine = !(tile_stride > 1 && (t % tile_stride) != tile_offset);
+        if (!mine) {  // another rank's row tile: nothing of it is added to this partial
+            if (!sym) HIP_CHECK(c, hipMemsetAsync(out + i0, 0, (size_t)nr * sizeof(T), c->stream));
             continue;
         }
-        for (int64_t j0 = 0; j0 < N; j0 += TILE) {
+        for (int64_t j0 = sym ? i0 : 0; j0 < N; j0 += TILE) {
             const int64_t nc = std::min(TILE, N - j0);
             CGLB_TRY(gram_tile<T>(c, XsRow + i0 * c->D, nr, (const T*)c->Xs + j0 * c->D, nc, G, nr));
             const int nslice = (int)((nc + CSLICE - 1) / CSLICE);
-            hipLaunchKernelGGL((wide_rowsum_kernel<T, KIND>), dim3((unsigned)((nr + 255) / 256), (unsigned)nslice), dim3(256), 0, c->stream, (const T*)G, nr, nr, nc,
-                               xaRow + i0, (const T*)c->xa + j0, p_full + j0, (T*)c->wpart);
+            const unsigned gx = (unsigned)((nr + 255) / 256);
+            const bool both = sym && j0 > i0;
+            if (both)
+                hipLaunchKernelGGL((wide_rowcol_kernel<T, KIND>), dim3(gx, (unsigned)nslice), dim3(256), 0, c->stream, (const T*)G, nr, nr, nc, xaRow + i0,
+                                   (const T*)c->xa + j0, p_full + i0, p_full + j0, part, pcpart);
+            else
+                hipLaunchKernelGGL((wide_rowsum_kernel<T, KIND>), dim3(gx, (unsigned)nslice), dim3(256), 0, c->stream, (const T*)G, nr, nr, nc, xaRow + i0,
+                                   (const T*)c->xa + j0, p_full + j0, part);
             const bool last = j0 + TILE >= N;
-            hipLaunchKernelGGL((wide_rowsum_reduce_kernel<T>), dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream, (const T*)c->wpart, nslice, nr, (T)c->var,
-                               out + i0, j0 > 0 ? 1 : 0, (T)c->noise, (diag_noise && last) ? p_full + row0_global + i0 : (const T*)nullptr);
+            // sym: `out` was zeroed and every tile accumulates; otherwise the first column tile overwrites
+            hipLaunchKernelGGL((wide_rowsum_reduce_kernel<T>), dim3(gx), dim3(256), 0, c->stream, (const T*)part, nslice, nr, (T)c->var, out + i0,
+                               (sym || j0 > 0) ? 1 : 0, (T)c->noise, (diag_noise && last) ? p_full + row0_global + i0 : (const T*)nullptr);
+            if (both)
+                hipLaunchKernelGGL((wide_rowsum_reduce_kernel<T>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, (const T*)pcpart, (int)(gx * 4), nc,
+                                   (T)c->var, out + j0, 1, (T)0, (const T*)nullptr);
             CGLB_LAUNCH_CHECK(c);
         }
     }

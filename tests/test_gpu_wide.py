@@ -102,7 +102,7 @@ def _dist_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cglb_amd.dist_context import DistHipContext
-        N, D, M = 9000, 40, 32       # three 4096-row tiles: dealt 2 + 1 over the two ranks
+        N, D, M = 9000, 40, 128      # three 4096-row tiles: dealt 2 + 1 over the two ranks; 22 CG steps
         X, y, Z, hyp = _problem(N, D, M, seed=3)
         ctx = DistHipContext(X, y, M, "rbf", collectives="callbacks")
         ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
@@ -125,12 +125,12 @@ def test_wide_inputs_on_two_ranks():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    N, D, M = 9000, 40, 32
+    N, D, M = 9000, 40, 128
     X, y, Z, hyp = _problem(N, D, M, seed=3)
     cov = orc.dense_cov("rbf", X, hyp)
     ref = orc.objective("rbf", X, y, hyp, np.zeros(N), True, 1.0, 100, 40, cov=cov)
     for rank, steps, bound, v, grad in out:
-        assert abs(steps - ref.steps) <= (0 if ref.steps <= 40 else 1), rank      # 60 steps: beyond the first restart
+        assert steps == ref.steps and ref.steps == 22, rank
         refg = orc.objective("rbf", X, y, hyp, v, run_cg=False, with_grad=True, cov=cov)
         assert bound == pytest.approx(refg.bound, rel=1e-10)
         np.testing.assert_allclose(grad["lengthscales"], refg.grad["lengthscales"], rtol=0, atol=1e-7 * np.abs(refg.grad["lengthscales"]).max())
