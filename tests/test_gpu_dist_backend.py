@@ -369,3 +369,57 @@ def test_a_rank_without_rows_takes_part_in_every_collective():
         np.testing.assert_allclose(pv, ov, rtol=0, atol=1e-10 * np.abs(ov).max())
     conv = orc.objective("matern32", X, y, hyp, np.zeros(4), True, 1e-8)
     assert abs(out[0][1] - conv.steps) <= 1 and out[0][2] == pytest.approx(conv.bound, rel=1e-8)
+
+
+# ------------------------------------------------------------------------- the backend API over the nccl (= RCCL) process group, world 1
+def _nccl_backend_worker(rank, world, port, path, tmp, q):
+    os.environ["CGLB_FORCE_DIST"] = "1"        # take the N-rank path (DistHipContext, RCCL inside the library) at world size 1
+    dist = _init(rank, world, port, "nccl")
+    try:
+        from cglb_amd.backend import BACKENDS, CGLBConfig, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS
+        from cglb_amd.backend.callbacks import Logger
+        from cglb_amd.dist_context import DistHipContext
+        g = dict(np.load(path))
+        be = BACKENDS["hip"]
+        be.configure_backend(logdir=tmp, keops=False)
+        be.set_default_float("fp64")
+        be.set_default_jitter("fp64")
+        cfg = CGLBConfig(kernel=KERNEL_CONFIGS["rbf"](), inducing_variable=INDUCING_VARIABLE_CONFIGS["cv"](g["init_Z"].shape[0]))
+        model = be.create_model(cfg, (g["X"], g["y"]))
+        assert isinstance(model.hip, DistHipContext) and model.hip.collectives == "rccl"
+        model.likelihood.noise = float(g["init_noise"])
+        model.covar_module.base_kernel.base_kernel.lengthscale = g["init_lengthscales"]
+        model.covar_module.base_kernel.outputscale = float(g["init_variance"])
+        with torch.no_grad():
+            model.mean_module.constant.copy_(torch.tensor(float(g["init_mean"]), dtype=torch.float64))
+            model.covar_module.inducing_points.copy_(torch.from_numpy(g["init_Z"]))
+        test = (g["X"][:40], g["y"][:40])
+        mfn = be.metrics_fn(model, ((g["X"], g["y"]), test))
+        logger = Logger(tmp, mfn, lambda: be.model_parameters(model), holdout_interval=5, include_feval_log=True, verbose=False)
+        losses = []
+        orig = logger.log_for_feval
+
+        def record(**entries):
+            orig(**entries)
+            losses.append(-float(model.last_bound))
+        logger.log_for_feval = record
+        results = be.optimize(model, ((g["X"], g["y"]), test), int(g["num_steps"]), logger, "scipy")
+        metrics = {k: float(np.asarray(v)) for k, v in mfn().items()}
+        q.put((rank, losses, list(logger.logs["steps-per-feval"]), [int(r.nit) for r in results], metrics,
+               model.hip.get_stat("comm_allreduce_calls"), model.hip.get_stat("comm_allgather_calls")))
+        model.hip.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_backend_api_over_the_rccl_process_group_world1(tmp_path):
+    """create_model / optimize / metrics_fn with torch.distributed's nccl backend initialised (world size 1, N-rank path forced):
+    parameter broadcast, rank-agreement check and every collective of training and prediction go through RCCL; the trajectory is the
+    reference optimiser's."""
+    path = os.path.join(GOLDEN_DIR, "train", "train_rbf_d8_trained.npz")
+    g = dict(np.load(path))
+    (_, losses, steps, nit, metrics, n_ar, n_ag), = _spawn(_nccl_backend_worker, 1, (path, str(tmp_path)), 1)
+    np.testing.assert_allclose(losses, g["loss"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(np.asarray(steps, dtype=np.int64), g["steps"][1:])
+    assert nit == g["nit"].tolist()
+    assert n_ar > 100 and n_ag > 50 and all(np.isfinite(list(metrics.values())))
