@@ -15,7 +15,7 @@ be = BACKENDS["hip"]
 be.configure_backend(logdir="/tmp/cglb_train_timing", keops=False)
 be.set_default_float("fp64"); be.set_default_jitter("fp64")
 t0 = time.perf_counter()
-model = be.create_model(CGLBConfig(kernel=KERNEL_CONFIGS["rbf"](), inducing_variable=INDUCING_VARIABLE_CONFIGS["cv"](M)), (X, y))
+model = be.create_model(CGLBConfig(kernel=KERNEL_CONFIGS[os.environ.get("KERNEL", "rbf")](), inducing_variable=INDUCING_VARIABLE_CONFIGS["cv"](M)), (X, y))
 torch.cuda.synchronize(); t_create = time.perf_counter() - t0
 data = ((X, y), (X[:1000], y[:1000]))
 logger = Logger("/tmp/cglb_train_timing", be.metrics_fn(model, data), lambda: be.model_parameters(model), holdout_interval=10**9, verbose=False)
