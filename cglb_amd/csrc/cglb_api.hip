@@ -880,7 +880,8 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
         c->eval_profile = value != 0;
     }
     else if (!strcmp(name, "precision")) {
-        if (value != CGLB_PREC_EXACT && value != CGLB_PREC_FAST) return cglb_fail(c, CGLB_ERR_BAD_ARG, "precision must be 0 (exact) or 1 (fast)");
+        if (value != CGLB_PREC_EXACT && value != CGLB_PREC_FAST && value != CGLB_PREC_LOW)
+            return cglb_fail(c, CGLB_ERR_BAD_ARG, "precision must be 0 (exact), 1 (fast, default) or 2 (low)");
         c->precision = (int)value;
     }
     else if (!strcmp(name, "drop_weighted_operand")) c->pwh_src = nullptr;  // the vector last written by cglb_vec_update_p_seg is about to change

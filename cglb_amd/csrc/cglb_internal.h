@@ -141,7 +141,7 @@ struct cglb_ctx {
     size_t gpart_cap = 0;
     double* gradbuf = nullptr;     // device packed gradient [GRAD_LEN]
     // tunables
-    int precision = 1;  // CGLB_PREC_FAST (devmath.h): kernel values to <= 1e-13; 0 = CGLB_PREC_EXACT (~3e-16)
+    int precision = 1;  // CGLB_PREC_FAST (devmath.h): kernel values to <= 1e-13; 0 = CGLB_PREC_EXACT (~3e-16); 2 = CGLB_PREC_LOW (~1e-10, opt-in)
     int kff_variant = 2, kff_jsplit = 0, kff_rows = 4;  // 0 plain, 1 matrix-pipe Gram (fp64), 2 symmetric (default)
     bool exp_clamp = false;         // scaled operands so large that 2^x needs the range clamp (set by set_hypers)
     double m32_bias = 0.0;          // Matern-3/2: positivity bias of the squared distance in hot units^2 (devmath.h CGLB_M32_BIAS_*; set by set_hypers)

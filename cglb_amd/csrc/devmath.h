@@ -78,6 +78,9 @@ __device__ __forceinline__ float sqrt_pos(float x) { return __builtin_sqrtf(fmax
 // of the pair stream is ~5 % of the mat-vec (the kernels are bound by vector-fp64 issue).
 #define CGLB_PREC_EXACT 0
 #define CGLB_PREC_FAST 1
+//   CGLB_PREC_LOW   (2): degree-2 polynomial (1.0e-10): kernel values to ~1e-10 - inside north_star's 1e-6 on the bound, outside the
+//                        1e-10 the parity tests hold the default level to: opt-in only (one instruction per pair less than FAST).
+#define CGLB_PREC_LOW 2
 
 // Hot-loop square root for a squared distance that may come out slightly negative (Gram form): the clamp to a tiny positive
 // number replaces both the max(.,0) and the x > 0 select; sqrt_hot(d2 <= 0) = 2e-140, which the Matern profile maps to 1.
@@ -136,6 +139,11 @@ template <int PREC> __device__ __forceinline__ double exp2_tab_poly(double s) {
         p = __builtin_fma(p, s, 0x1.eb517b4ddbd98p-19);
         p = __builtin_fma(p, s, 0x1.6269464576054p-9);
         return __builtin_fma(p, s, 0x1.ff4eaca4391b6p-1);
+    }
+    if (PREC == CGLB_PREC_LOW) {  // degree 2: max. rel. error 1.03e-10 (tools/exp2_poly_fit.py)
+        double p = 0x1.ebfbe3a9ac80bp-19;
+        p = __builtin_fma(p, s, 0x1.6269364acae25p-9);
+        return __builtin_fma(p, s, 0x1.ff4eaca51c5ffp-1);
     }
     double p = 0x1.c6b0902b5a0abp-29;
     p = __builtin_fma(p, s, 0x1.eb5162aec6f78p-19);

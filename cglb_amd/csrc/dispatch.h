@@ -35,6 +35,7 @@
 #define CGLB_DISPATCH_PREC(c, ...)                                                                                   \
     if constexpr (sizeof(T) == 4) { constexpr int PREC = CGLB_PREC_EXACT; __VA_ARGS__; }                             \
     else if ((c)->precision == CGLB_PREC_EXACT) { constexpr int PREC = CGLB_PREC_EXACT; __VA_ARGS__; }               \
+    else if ((c)->precision == CGLB_PREC_LOW) { constexpr int PREC = CGLB_PREC_LOW; __VA_ARGS__; }                   \
     else { constexpr int PREC = CGLB_PREC_FAST; __VA_ARGS__; }
 
 #define CGLB_DISPATCH_ALL(c, ...) \

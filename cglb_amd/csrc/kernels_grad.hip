@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, (DP == CGLB_GRAM_W3_DP ? 3 : 1)) void grad_kff
     // column-side copies uc = u o w, vc = v o w of the two vectors (the row side uses u, v themselves), so the per-pair add of a_j is dropped
     constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP && sizeof(T) == 8;
     // Matern-3/2, fast level, unclamped range: positivity bias in the row seeds instead of a clamp per pair (devmath.h CGLB_M32_BIAS_*)
-    constexpr bool BIASED = (KIND != CGLB_RBF) && !CLAMP && PREC == CGLB_PREC_FAST && sizeof(T) == 8;
+    constexpr bool BIASED = (KIND != CGLB_RBF) && !CLAMP && PREC != CGLB_PREC_EXACT && sizeof(T) == 8;
     const int64_t rblock = ((int64_t)blockIdx.x * rb_stride + rb_offset) * (256 * R);  // cyclic over ranks when rb_stride > 1
     const int64_t rbase = rblock + threadIdx.x;
     __shared__ T trbuf[4 * 8 * GRAD_TR_LD];

@@ -53,7 +53,7 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
                                              T* __restrict__ Prow, T* __restrict__ cs, T* __restrict__ tr, const double* __restrict__ tab, int lane, T bias) {
     constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP;
     // Matern-3/2, fast level, unclamped range: squared distances kept positive by a bias in the row seeds instead of a clamp per pair
-    constexpr bool BIASED = (KIND != CGLB_RBF) && !CLAMP && PREC == CGLB_PREC_FAST && sizeof(T) == 8;
+    constexpr bool BIASED = (KIND != CGLB_RBF) && !CLAMP && PREC != CGLB_PREC_EXACT && sizeof(T) == 8;
     constexpr int RBROWS = 64 * R;
     const int64_t rbase = rb * RBROWS;
     // fp32: rows in pairs, so that the Gram chain and the two accumulations run as v_pk_fma_f32 (4.8 nominal cycles per pair of

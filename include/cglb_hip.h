@@ -248,7 +248,8 @@ int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
 /* Tunables: name = "kff_variant" | "kff_jsplit" | "kff_rows" | "sym_chunk" | "precond_mode" | "chol_mode" | "pcg_lookahead" | "sym_order" | "aat_block" | "grad_gram" | "k1_profile" |
  * "grad_trsm" (gradient algebra against L = chol(K_uu): 0 products with the explicit inverse, 1 backward-stable triangular solves, 2 = default:
  *  the products followed by one step of iterative refinement against L - the accuracy of the solves for about two thirds of their time) |
- * "precision" (1, default: kernel values to <= 1e-13 relative - degree-3 table polynomial, one-step square root; 0: ~3e-16) ...;
+ * "precision" (1, default: kernel values to <= 1e-13 relative - degree-3 table polynomial, one-step square root; 0: ~3e-16; 2: opt-in, degree-2
+ *  polynomial, kernel values to ~1e-10 - inside the 1e-6 the bound needs, one instruction per pair cheaper) ...;
  * "pcg_lookahead" (0: the host waits for the stop statistic before enqueuing anything; 1, default: the next mat-vec is enqueued first while
  *  1/2 r^T P r of the previous iteration exceeds 32 x max_error; k >= 2: that factor - a mis-speculated mat-vec is wasted work, never a wrong result) |
  * "final_matvec" (cglb_objective_and_grad after a solve: 1 recomputes K v with a mat-vec like models.py:280; 0, the default, takes K v = e - r
