@@ -125,6 +125,37 @@ def test_c5_n1m_d16_rbf_m4096_fp32():
     ctx.close()
 
 
+def test_c5_fp32_evaluation_against_the_fp64_path_at_full_size():
+    """C5 at its size: the CPU oracle cannot give a bound here (52 CPU-minutes per mat-vec), but the fp64 HIP path - pinned at the
+    headline, C2, C3 and C4 sizes by reference-solver fixtures - can: the same evaluation (3 CG steps from v = 0, N = 1 000 000, D = 16,
+    M = 4096) in fp64 and in fp32, bound / lower / upper / log-det and the gradient blocks compared at fp32 tolerances."""
+    from cglb_amd.hip_context import HipContext
+    N, D, M = 1_000_000, 16, 4096
+    X, y, Z = orc.synthetic_problem(N, D, M, seed=0)
+    hyp = orc.trained_like_hypers(D, Z)
+    hyp.jitter = 1e-5
+    out = {}
+    for dt in (torch.float64, torch.float32):
+        ctx = HipContext(X, y, M, "rbf", dtype=dt)
+        ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+        v = torch.zeros(N, dtype=dt, device=ctx.device)
+        out[dt] = (ctx.objective_and_grad(v, True, 1.0, 3, 40), v.double().cpu().numpy())
+        ctx.close()
+        del ctx, v
+        torch.cuda.empty_cache()
+    (r64, v64), (r32, v32) = out[torch.float64], out[torch.float32]
+    assert r64.steps == r32.steps == 3
+    assert r32.logdet == pytest.approx(r64.logdet, rel=1e-4)
+    assert r32.lower == pytest.approx(r64.lower, rel=1e-3) and r32.upper == pytest.approx(r64.upper, rel=1e-3)
+    assert r32.bound == pytest.approx(r64.bound, rel=1e-3)
+    np.testing.assert_allclose(v32, v64, rtol=0, atol=2e-3 * np.abs(v64).max())
+    for key in ("lengthscales", "Z"):
+        a, b = np.asarray(r32.grad[key]), np.asarray(r64.grad[key])
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-2 * np.abs(b).max(), err_msg=key)
+    for key in ("variance", "noise"):
+        assert r32.grad[key] == pytest.approx(r64.grad[key], rel=2e-2, abs=1e-3 * abs(r64.bound)), key
+
+
 def test_midsize_full_objective_and_gradient_vs_dense_oracle():
     """N = 16 500 (65 row blocks of 256, ragged last one; chunk-halving, XCD-aware item order and the multi-slab combine all
     active), D = 8, M = 256, trained-like hypers: the whole evaluation against the dense numpy oracle."""
