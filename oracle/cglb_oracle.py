@@ -246,7 +246,7 @@ class Sensitivity:
 
 def roundoff_sensitivity(kind, X, y, hyp: Hypers, v0: np.ndarray, max_error: float = 1.0, max_cg_iter: int = 100,
                          restart_cg_iter: int = 40, delta: float = 2.0 ** -52, probes: int = 4, seed: int = 0,
-                         cov: Optional[np.ndarray] = None) -> Sensitivity:
+                         cov: Optional[np.ndarray] = None, calibrate: Optional[Tuple[np.ndarray, float]] = None) -> Sensitivity:
     """Parity criterion for CG-path quantities, derived instead of tuned.  A PCG solve is a chaotic map once Lanczos orthogonality is
     lost (weak preconditioner, tens of steps): two CORRECT implementations whose mat-vecs agree to `delta` relative end at bounds that
     differ by far more than `delta`, and may stop one step apart when the stop statistic passes the tolerance within its own noise.
@@ -276,9 +276,15 @@ def roundoff_sensitivity(kind, X, y, hyp: Hypers, v0: np.ndarray, max_error: flo
     rng = np.random.default_rng(seed)
     b_spread, s_spread = 0.0, 0
     rel = np.zeros(len(h0))
-    for _ in range(probes):
+    for probe in range(probes):
         E = rng.uniform(-1.0, 1.0, size=(N, N))
         E = np.triu(E) + np.triu(E, 1).T
+        if probe == 0 and calibrate is not None:
+            pc, target = calibrate
+            ref_mv = cov @ pc
+            dev = float(np.abs((cov * E) @ pc).max() / np.abs(ref_mv).max())   # deviation per unit amplitude
+            if dev > 0.0:
+                delta = max(delta, float(target) / dev)
         covp = cov * (1.0 + delta * E)
         del E
         hp: list = []
