@@ -793,6 +793,7 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     c->N = n_total; c->r0 = row_begin; c->r1 = row_end; c->nloc = row_end - row_begin;
     c->lda = (c->nloc + 7) & ~(int64_t)7; if (c->lda == 0) c->lda = 8;
     c->D = d; c->Dp = pad_dim(d); c->M = m; c->dtype = dtype; c->kind = kernel_kind; c->device = device;
+    c->Dh = mid_dim(d, dtype);
     c->esz = dtype == CGLB_F64 ? 8 : 4; c->stream = (hipStream_t)stream;
     auto fail = [&](int rc) { g_create_error = c->err; cglb_ctx_destroy(c); return rc; };
 #define CR(expr) do { int _rc = (expr); if (_rc != CGLB_OK) return fail(_rc); } while (0)
@@ -805,7 +806,7 @@ int cglb_ctx_create(cglb_ctx** out, int64_t n_total, int64_t row_begin, int64_t 
     CR(dalloc(c, &c->Zh, M * Dp * e)); CR(dalloc(c, &c->zah, M * e)); CR(dalloc(c, &c->Linv, M * M * e)); CR(dalloc(c, &c->LinvT, M * M * e));
     CR(dalloc(c, &c->w_q, M * e));
     const size_t hotN = c->Dp > CGLB_MAX_D_NARROW ? 0 : N;  // the hot operand set exists for the register-resident pair kernels only
-    CR(dalloc(c, &c->Xh, hotN * Dp * e)); CR(dalloc(c, &c->Xhsq, hotN * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, &c->wh, N * e)); CR(dalloc(c, &c->pwh, N * e)); CR(dalloc(c, (void**)&c->exp_tab, CGLB_TAB_SIZE * sizeof(double)));
+    CR(dalloc(c, &c->Xh, c->Dh > 0 ? N * (size_t)c->Dh * e : hotN * Dp * e)); CR(dalloc(c, &c->Xhsq, hotN * Dp * e)); CR(dalloc(c, &c->xah, N * e)); CR(dalloc(c, &c->wh, N * e)); CR(dalloc(c, &c->pwh, N * e)); CR(dalloc(c, (void**)&c->exp_tab, CGLB_TAB_SIZE * sizeof(double)));
     {   // 2^x table of the pair kernels: 2^((k + 1/2)/T) for the floor/fract range reduction (devmath.h)
         std::vector<double> tab(CGLB_TAB_SIZE);
         for (int k = 0; k < CGLB_TAB_SIZE; ++k) {
@@ -886,6 +887,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
     }
     else if (!strcmp(name, "drop_weighted_operand")) c->pwh_src = nullptr;  // the vector last written by cglb_vec_update_p_seg is about to change
     else if (!strcmp(name, "final_matvec")) c->final_matvec = (int)value;
+    else if (!strcmp(name, "wide_reg")) { c->wide_reg = (int)value; c->pwh_src = nullptr; }
     else if (!strcmp(name, "chol_mode")) c->chol_mode = (int)value;
     else if (!strcmp(name, "grad_trsm")) c->grad_trsm = (int)value;
     else if (!strcmp(name, "precond_mode")) { c->precond_mode = (int)value; c->have_local = c->have_terms = false; }
@@ -962,6 +964,10 @@ int cglb_set_hypers(cglb_ctx* c, const double* lengthscales, double variance, do
     }
     if (is_wide(c)) {  // D > 32: one scaled operand set (+ its squares), Gram products through rocBLAS (kernels_wide.hip)
         CGLB_TRY(wide_after_hypers(c));
+        if (c->Dh > 0) {   // mid width: the symmetric mat-vec stays register-resident (kernels_kff_sym.hip) and needs its hot operands
+            CGLB_TRY(wide_prep_hot(c));
+            CGLB_TRY(launch_hot_weights(c));
+        }
     } else {
         CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xs, c->xa));
         CGLB_TRY(launch_prep_scaled(c, c->X, c->N, c->Xh, c->xah, true));

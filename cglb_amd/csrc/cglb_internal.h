@@ -13,6 +13,7 @@
 
 #define CGLB_MAX_D 1024        // widest input the context accepts (host-side arrays)
 #define CGLB_MAX_D_NARROW 32   // widest input of the register-resident pair kernels; beyond it the "wide" path runs (kernels_wide.hip)
+#define CGLB_MAX_D_MID 96     // ... except the symmetric K_ff mat-vec (fp64): up to here it still runs register-resident, the Gram chain in 16-wide slices
 #define CGLB_WAVE 64
 
 // Collectives of the N-rank path inside the library (cglb_comm_init_*, cglb_dist_*; include/cglb_hip.h): RCCL on the context stream, or
@@ -42,6 +43,8 @@ struct cglb_ctx {
     // geometry
     int64_t N = 0, r0 = 0, r1 = 0, nloc = 0, lda = 0;  // lda: leading dimension of At/Guf (nloc rounded up to 8)
     int D = 0, Dp = 0, M = 0, dtype = CGLB_F64, kind = CGLB_RBF, device = 0;
+    int Dh = 0;        // 32 < D <= 96, fp64: padded width (48, 64, 80, 96) of the hot operand set Xh kept for the register-resident mat-vec
+    int wide_reg = 1;  // option "wide_reg": 0 sends that mat-vec through the Gram tiles of kernels_wide.hip as well (A/B, fallback)
     size_t esz = 8;
     hipStream_t stream = nullptr;
     rocblas_handle blas = nullptr;
@@ -195,11 +198,18 @@ static inline int pad_dim(int d) {
 static inline bool is_wide(const cglb_ctx* c);
 
 static inline bool is_wide(const cglb_ctx* c) { return c->Dp > CGLB_MAX_D_NARROW; }
+// padded width of the hot operand set of a mid-width fp64 context (0: none)
+static inline int mid_dim(int d, int dtype) {
+    if (dtype != CGLB_F64 || d <= CGLB_MAX_D_NARROW || d > CGLB_MAX_D_MID) return 0;
+    return d <= 48 ? 48 : d <= 64 ? 64 : d <= 80 ? 80 : 96;  // (a 128-wide row operand alone would fill the 256 VGPRs VALU instructions can address)
+}
+static inline bool mid_reg(const cglb_ctx* c) { return c->Dh > 0 && c->wide_reg != 0; }
 
 // kernels_wide.hip: D > 32.  The Gram part of the pair value is a contraction with k = D and goes through rocBLAS in tiles; same
 // contracts as the launchers below they stand in for.
 int wide_prep_scaled(cglb_ctx* c, const void* Xraw, int64_t n, void* Xs_out, void* xa_out, void* Xsq_out);
 int wide_after_hypers(cglb_ctx* c);
+int wide_prep_hot(cglb_ctx* c);   // Xh (N x Dh, zero padded), xah in hot units for the register-resident mat-vec of a mid-width context
 int wide_kuf(cglb_ctx* c);
 int wide_kuu(cglb_ctx* c);
 int wide_kus(cglb_ctx* c, const void* XsNew, const void* xaNew, int64_t n_new, int64_t ld, void* out);
@@ -223,6 +233,7 @@ int launch_cholesky_lower(cglb_ctx* c, void* A, int* info_slot);
 int launch_frag_prep(cglb_ctx* c);
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
 int launch_hot_weights(cglb_ctx* c);
+int launch_kff_sym_mid(cglb_ctx* c, const void* p_full, void* out, double* pdot_slot, bool cyclic);  // 32 < D <= 96, fp64 (kernels_kff_sym.hip)
 int launch_hot_squares(cglb_ctx* c);  // Xhsq = Xh .* Xh after set_hypers
 int k1_profile_collect(cglb_ctx* c);  // resolves the pending event pairs into k1_ms_total / k1_launches  // wh = 2^(xah/T) after set_hypers (RBF)
 int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial);  // this rank's share of the global upper triangle

@@ -255,6 +255,48 @@ template <bool CLAMP, int PREC> __device__ __forceinline__ float exp2_tab(float 
     return __builtin_amdgcn_exp2f(xh * (1.0f / (float)CGLB_TAB_SIZE));
 }
 
+// acc += (lane 16 (l / 16) + K of bc) * x: v_fmac_f64 with the DPP control row_newbcast (gfx90a+).  One VGPR pair whose lane l holds operand
+// l % 16 hands 16 different wave-uniform operands to 16 consecutive fmas at the full fma rate (tools/microbench/dpp_fmac.hip:
+// 4.9-5.2 nominal cycles per instruction for both forms) - the operand path of the mid-width kernels (32 < D <= 96: kernels_kff_sym.hip, kernels_grad.hip), whose
+// columns no longer fit the scalar register file.
+template <int K> __device__ __forceinline__ void fmac_bcast(double& acc, double bc, double x) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(x), "n"(K));
+}
+template <int K0, int N> struct BcastChain {   // acc += sum_{k < N} bc[lane k] * x[k]
+    static __device__ __forceinline__ void run(double& acc, double bc, const double* x) {
+        fmac_bcast<K0>(acc, bc, x[K0]);
+        if constexpr (K0 + 1 < N) BcastChain<K0 + 1, N>::run(acc, bc, x);
+    }
+};
+template <int K0, int N> struct BcastChain2 {  // two interleaved chains (even / odd k): for the instances that run one wave per SIMD
+    static __device__ __forceinline__ void run(double& a0, double& a1, double bc, const double* x) {
+        fmac_bcast<K0>(a0, bc, x[K0]);
+        fmac_bcast<K0 + 1>(a1, bc, x[K0 + 1]);
+        if constexpr (K0 + 2 < N) BcastChain2<K0 + 2, N>::run(a0, a1, bc, x);
+    }
+};
+template <int K0, int N> struct BcastAxpy {    // acc[k] += bc[lane k] * x for k < N (the moment accumulation of the gradient pass)
+    static __device__ __forceinline__ void run(double* acc, double bc, double x) {
+        fmac_bcast<K0>(acc[K0], bc, x);
+        if constexpr (K0 + 1 < N) BcastAxpy<K0 + 1, N>::run(acc, bc, x);
+    }
+};
+// sum of a value over the two 32-lane halves of the wave, returned to both (v_permlane32_swap, gfx950): with old == src the first result is
+// the lower half's value in every lane, the second the upper half's
+__device__ __forceinline__ double sum_halves(double g) {
+    const unsigned lo = (unsigned)__double2loint(g), hi = (unsigned)__double2hiint(g);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+// sum over the 16-lane rows 2 q and 2 q + 1, returned to both (v_permlane16_swap: odd rows of the first operand <-> even rows of the second)
+__device__ __forceinline__ double sum_row_pairs(double g) {
+    const unsigned lo = (unsigned)__double2loint(g), hi = (unsigned)__double2hiint(g);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
 template <typename T> __device__ __forceinline__ T tfma(T a, T b, T c);
 template <> __device__ __forceinline__ double tfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <> __device__ __forceinline__ float tfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

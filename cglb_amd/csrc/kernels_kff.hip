@@ -342,6 +342,7 @@ int launch_kff_plain_range(cglb_ctx* c, const void* p_full, int64_t col0, int64_
 // out_local = K_ff[rows,:] p + noise p[rows]; if pdot_slot != null also sum_i p_i out_i over local rows.
 int launch_kff_matvec(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot) {
     if (c->nloc == 0) return CGLB_OK;
+    if (is_wide(c) && mid_reg(c) && c->nloc == c->N) return launch_kff_sym_mid(c, p_full, out_local, pdot_slot, false);
     if (is_wide(c))
         return wide_matvec(c, (const char*)c->Xs + (size_t)c->r0 * c->Dp * c->esz, (const char*)c->xa + (size_t)c->r0 * c->esz, c->r0, c->nloc, p_full, out_local, true,
                            pdot_slot, 1, 0);

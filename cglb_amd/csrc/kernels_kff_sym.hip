@@ -36,7 +36,10 @@ typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane
 #define CGLB_SYM_TR_REG 0
 #endif
 // minimum waves per SIMD asked of the compiler for the fp64 instances (padded width DP, R rows per lane); 1 = no constraint
-#define CGLB_SYM_WAVES(DP, R) (((DP) <= 8 && (R) <= 4) ? 3 : ((DP) == 32 ? 4 : 1))
+#define CGLB_SYM_WAVES(DP, R) (((DP) <= 8 && (R) <= 4) ? 3 : ((DP) == 32 ? 4 : ((DP) == 96 ? CGLB_SYM_WAVES_96 : 1)))
+#ifndef CGLB_SYM_WAVES_96
+#define CGLB_SYM_WAVES_96 2
+#endif
 #ifndef CGLB_SYM_R4_MAX_DP
 #define CGLB_SYM_R4_MAX_DP 12  // widest padded row that still gets 4 rows per lane in fp64 (DP = 12: 3.67 -> 3.40 ms at N = 100k against 2 rows)
 #endif
@@ -59,6 +62,17 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
     // fp32: rows in pairs, so that the Gram chain and the two accumulations run as v_pk_fma_f32 (4.8 nominal cycles per pair of
     // fma against 2 x 2.94 unpacked); the column operand is broadcast to both halves through op_sel straight from the SGPR
     constexpr bool PACKED = (sizeof(T) == 4) && (R % 2 == 0);
+    // Mid width (32 < DP <= 96, fp64, R = 1): the row operand fills 2 DP VGPRs and a column's operands no longer fit the scalar register
+    // file (first attempt: 16-wide slices through a double buffer of 64 SGPRs - the scalar loads of a 650-KB column chunk miss the scalar
+    // cache and one slice of lead, 64 cycles, does not cover them: 11.4 ms at N = 50k, D = 77 against 11.8 through the Gram tiles).  The
+    // column operands therefore travel in VGPRs: slice s of a column is ONE register pair, lane l holding coordinate 16 s + l % 16 (a vector
+    // load of 128 bytes), and the fma takes coordinate k from lane k of its 16-lane row (devmath.h: fmac_bcast).  Vector loads return in
+    // order, so the compiler's vmcnt waits for the look-ahead are exact.
+    constexpr bool MID = DP > 32;
+    constexpr int CH = 16, NCH = MID ? DP / CH : 1, DJ = MID ? 1 : DP;
+    constexpr bool MID2 = MID && DP > 80;   // one wave per SIMD (VGPR budget): two interleaved chains instead of one
+    static_assert(!MID || (R == 1 && sizeof(T) == 8 && DP % CH == 0), "mid-width instances: fp64, one row per lane, width a multiple of 16");
+    const int l16 = lane & 15;
     constexpr int RP = PACKED ? R / 2 : 1;
     constexpr int RU = PACKED ? 1 : R;  // the unpacked row operands exist only on the other path
     T xi[RU][DP], ai[R], pr[R], acc[R];
@@ -95,13 +109,19 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
     const int64_t jfull = j0 + ((j1 - j0) / SYM_BATCH) * SYM_BATCH;
     // Column operands are software-pipelined one column ahead: the scalar loads of column j+1 are issued before the
     // arithmetic of column j, so their latency (and that of the table reads, which share the lgkm counter) is covered.
-    T xj[DP], aj = T(0), pj;
+    T xj[DJ], aj = T(0), pj;
+    T xsl[NCH];  // MID: the slices of the current column
     if (j0 < jfull) {
         const int64_t j = row0 + j0;
         if (!FOLD) aj = xa[j];
         pj = pc[j];
+        if constexpr (MID) {
 #pragma unroll
-        for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
+            for (int sl = 0; sl < NCH; ++sl) xsl[sl] = Xs[j * DP + sl * CH + l16];
+        } else {
+#pragma unroll
+            for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
+        }
     }
     for (int64_t jb = j0; jb < jfull; jb += SYM_BATCH) {
         const T* __restrict__ xsj = Xs + (row0 + jb) * DP;  // wave-uniform bases: s_load with immediate offsets
@@ -116,9 +136,12 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
             // compiler then parks them in VGPR lanes (D = 32: 581 spilled SGPRs, 70 v_readlane/v_writelane per column: 6.4 ms for a
             // mat-vec at N = 60k that takes 3.2 without); the loads then have the 2^x and the accumulation of the column to land.
             constexpr bool LATE = DP >= CGLB_SYM_LATE_DP;
-            T xn[DP], an = T(0), pn;
+            T xn[DJ], an = T(0), pn;
             const int64_t o = (jj + 1 < SYM_BATCH) ? jj + 1 : nb;
-            if (!LATE) {
+            if constexpr (MID) {
+                if (!FOLD) an = xaj[o];
+                pn = pjv[o];
+            } else if (!LATE) {
                 if (!FOLD) an = xaj[o];
                 pn = pjv[o];
 #pragma unroll
@@ -126,7 +149,28 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
                 __builtin_amdgcn_sched_barrier(0);  // issue the prefetch first; it is consumed a whole column later
             }
             T gram[R];
-            if (PACKED) {
+            if constexpr (MID) {
+                // Slice s of the NEXT column is requested into the register pair slice s of this column just left: it is needed one whole
+                // column later, and no second set of registers is spent on the look-ahead.
+                if constexpr (MID2) {
+                    T g0 = ai[0], g1 = T(0);
+#pragma unroll
+                    for (int sl = 0; sl < NCH; ++sl) {
+                        BcastChain2<0, CH>::run(g0, g1, xsl[sl], &xi[0][sl * CH]);
+                        xsl[sl] = xsj[o * DP + sl * CH + l16];
+                    }
+                    gram[0] = g0 + g1;
+                } else {
+                    T g = ai[0];
+#pragma unroll
+                    for (int sl = 0; sl < NCH; ++sl) {
+                        BcastChain<0, CH>::run(g, xsl[sl], &xi[0][sl * CH]);
+                        xsl[sl] = xsj[o * DP + sl * CH + l16];
+                    }
+                    gram[0] = g;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (PACKED) {
 #pragma unroll
                 for (int rp = 0; rp < RP; ++rp) {
                     sym_f2 g = ai2[rp];
@@ -144,7 +188,7 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
                     gram[r] = g;
                 }
             }
-            if (LATE) {
+            if constexpr (LATE && !MID) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (!FOLD) an = xaj[o];
                 pn = pjv[o];
@@ -191,8 +235,10 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
             __builtin_amdgcn_sched_barrier(0);
             aj = an;
             pj = pn;
+            if constexpr (!MID) {
 #pragma unroll
-            for (int d = 0; d < DP; ++d) xj[d] = xn[d];
+                for (int d = 0; d < DP; ++d) xj[d] = xn[d];
+            }
         }
         if (jb >= sym_from) {  // wave-uniform
             // Column sums of the batch = sums ACROSS the 64 lanes of t[0..15].
@@ -250,15 +296,25 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
         const int64_t j = row0 + jc;
         const T aj = FOLD ? T(0) : xa[j];
         const T pj = pc[j];
-        T xj[DP];
+        T xj[DJ];
+        if constexpr (!MID) {
 #pragma unroll
-        for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
+            for (int d = 0; d < DP; ++d) xj[d] = Xs[j * DP + d];
+        }
         T tj = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             T gram = ai[r];
+            if constexpr (MID) {   // no prefetch: at most 15 columns per work item come this way
+                T ct[NCH];
+#pragma unroll
+                for (int sl = 0; sl < NCH; ++sl) ct[sl] = Xs[j * DP + sl * CH + l16];
+#pragma unroll
+                for (int sl = 0; sl < NCH; ++sl) BcastChain<0, CH>::run(gram, ct[sl], &xi[0][sl * CH]);
+            } else {
 #pragma unroll
             for (int d = 0; d < DP; ++d) gram = tfma<T>(PACKED ? (T)xi2[(r / 2) % RP][d][r % 2] : xi[r % RU][d], xj[d], gram);
+            }
             const T kap = kappa_hot_single<T, KIND, CLAMP, FOLD || BIASED, PREC>(gram, aj, tab);  // FOLD: the weight is in pj / applied below
             acc[r] = tfma<T>(kap, pj, acc[r]);
             tj = tfma<T>(kap, pr[r], tj);
@@ -391,7 +447,7 @@ __global__ __launch_bounds__(256) void weight_operand_kernel(const T* __restrict
     if (i < n) pw[i] = p[i] * wh[i];
 }
 int launch_hot_weights(cglb_ctx* c) {
-    if (c->kind != CGLB_RBF || is_wide(c)) return CGLB_OK;
+    if (c->kind != CGLB_RBF || (is_wide(c) && c->Dh == 0)) return CGLB_OK;
     const int grid = (int)((c->N + 255) / 256);
     CGLB_DISPATCH_T(c->dtype, hipLaunchKernelGGL((hot_weights_kernel<T>), dim3(grid), dim3(256), 0, c->stream, (const T*)c->xah, c->N, (T*)c->wh));
     CGLB_LAUNCH_CHECK(c);
@@ -613,6 +669,23 @@ int k1_profile_collect(cglb_ctx* c) {
     return CGLB_OK;
 }
 
+// mid-width contexts (cglb_internal.h: mid_dim): the same kernel on the Dh-wide hot operand set, Gram chain in slices
+#define CGLB_DISPATCH_DH(dh, ...)                                           \
+    switch (dh) {                                                           \
+        case 48: { constexpr int DP = 48; __VA_ARGS__; } break;             \
+        case 64: { constexpr int DP = 64; __VA_ARGS__; } break;             \
+        case 80: { constexpr int DP = 80; __VA_ARGS__; } break;             \
+        case 96: { constexpr int DP = 96; __VA_ARGS__; } break;             \
+        default: return cglb_fail(c, CGLB_ERR_BAD_ARG, "unsupported mid width"); \
+    }
+
+int launch_kff_sym_mid(cglb_ctx* c, const void* p_full, void* out, double* pdot_slot, bool cyclic) {
+    using T = double;
+    if (!cyclic && c->nloc != c->N) return cglb_fail(c, CGLB_ERR_STATE, "the register-resident mid-width mat-vec covers the full square or the cyclic deal only");
+    CGLB_DISPATCH_KIND(c->kind, CGLB_DISPATCH_DH(c->Dh, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out, pdot_slot, cyclic))));
+    return CGLB_OK;
+}
+
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot) {
     if (is_wide(c)) return launch_kff_matvec(c, p_full, out_local, pdot_slot);
     CGLB_DISPATCH_ALL(c, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out_local, pdot_slot, false)));
@@ -621,6 +694,7 @@ int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdo
 
 int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial) {
     // wide inputs: row tiles of the full square dealt round-robin to the ranks; every rank adds the noise term on its own rows
+    if (is_wide(c) && mid_reg(c)) return launch_kff_sym_mid(c, p_full, out_full_partial, nullptr, true);
     if (is_wide(c)) return wide_matvec(c, c->Xs, c->xa, 0, c->N, p_full, out_full_partial, true, nullptr, c->par_world, c->par_rank);
     CGLB_DISPATCH_ALL(c, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out_full_partial, nullptr, true)));
     return CGLB_OK;

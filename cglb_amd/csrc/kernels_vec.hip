@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void update_p_kernel(T* __restrict__ p, const 
 
 // wh/pw of the fused weighting: only for a full-length vector (all N rows) of a context whose symmetric kernel folds the column norm
 static inline bool fuse_weights(const cglb_ctx* c, int64_t n) {
-    return c->kind == CGLB_RBF && !c->exp_clamp && c->have_hypers && n == c->N;
+    return c->kind == CGLB_RBF && !c->exp_clamp && c->have_hypers && n == c->N && (!is_wide(c) || mid_reg(c));
 }
 
 // fuse: also write the weighted copy for the NEXT symmetric mat-vec of p.  Only for callers that own the loop (the fused PCG and the

@@ -68,6 +68,25 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(const T* __restrict__ X,
     if (lane == 0) xa[i] = (KIND == CGLB_RBF) ? (T)(-0.5 * s2) : (T)s2;
 }
 
+// Hot operand set of a mid-width context (32 < D <= 96, fp64): xh = (x - centre) * scale * hot, zero padded to Dh, a = |xh|^2 term -
+// the layout kernels_kff_sym.hip streams (one wave per row)
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void wide_prep_hot_kernel(const T* __restrict__ X, int64_t n, int D, int Dh, const double* __restrict__ center,
+                                                            const double* __restrict__ scale, double hot, T* __restrict__ Xh, T* __restrict__ xah) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    double s2 = 0.0;
+    for (int d = lane; d < Dh; d += 64) {
+        T v = T(0);
+        if (d < D) v = (T)(((double)X[i * D + d] - center[d]) * (scale[d] * hot));
+        Xh[i * Dh + d] = v;
+        s2 += (double)v * (double)v;
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) xah[i] = (KIND == CGLB_RBF) ? (T)(-0.5 * s2) : (T)s2;
+}
+
 // kernel value / derivative factor from a Gram entry.  MODE 0: kappa; 1: h with dk/dl_d = var h delta_d^2 / l_d (RBF: kappa; Matern-3/2: 3 2^(-r))
 template <typename T, int KIND, int MODE> __device__ __forceinline__ T wide_profile(T g, T ai, T aj) {
     if (KIND == CGLB_RBF) return exp2_neg(tmin<T>(ai + aj + g, T(0)));   // the exact exponent is <= 0; round-off may leave it a few ulp above
@@ -344,6 +363,15 @@ int wide_after_hypers(cglb_ctx* c) {
     CGLB_TRY(ensure_ones(c));
     CGLB_TRY(wide_prep_scaled(c, c->X, c->N, c->Xs, c->xa, c->Xsq));
     CGLB_TRY(wide_prep_scaled(c, c->Z, c->M, c->Zs, c->za, c->Zsq));
+    return CGLB_OK;
+}
+
+int wide_prep_hot(cglb_ctx* c) {   // after wide_after_hypers: the device copies of centre and scale are current
+    if (c->Dh == 0 || c->N == 0) return CGLB_OK;
+    CGLB_DISPATCH_T(c->dtype, CGLB_DISPATCH_KIND(c->kind, hipLaunchKernelGGL((wide_prep_hot_kernel<T, KIND>), dim3((unsigned)((c->N + 3) / 4)), dim3(256), 0, c->stream,
+                                                                             (const T*)c->X, c->N, c->D, c->Dh, (const double*)c->wcenter, (const double*)c->wscale,
+                                                                             cglb_hot_scale(c), (T*)c->Xh, (T*)c->xah)));
+    CGLB_LAUNCH_CHECK(c);
     return CGLB_OK;
 }
 

@@ -1,5 +1,7 @@
 """Inputs wider than 32 dimensions (the reference accepts any Wilson UCI set, datasets.py:47-76: buzz 77, song 90, slice 385 ...): the
-Gram part of the pair value goes through rocBLAS in tiles (cglb_amd/csrc/kernels_wide.hip).  Every seam against the dense oracle."""
+Gram part of the pair value goes through rocBLAS in tiles (cglb_amd/csrc/kernels_wide.hip); up to 96 dimensions (fp64) the two N^2
+passes - the symmetric K_ff mat-vec and the K_ff gradient pass - stay register-resident, their column operands handed out by
+v_fmac_f64 row_newbcast (kernels_kff_sym.hip / kernels_grad.hip, option "wide_reg").  Every seam against the dense oracle."""
 import os
 import socket
 
@@ -62,6 +64,43 @@ def test_wide_inputs_every_seam_against_the_oracle(kind, N, D, M):
     np.testing.assert_allclose(cm, orc.kernel_matrix(kind, xnew, X, hyp.lengthscales, hyp.variance) @ p, rtol=0, atol=1e-11 * np.abs(cm).max())
     ctx.close()
 
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+@pytest.mark.parametrize("D,ell_factor,precision", [(40, 1.0, 1), (64, 1.0, 0), (77, 1.0, 1), (90, 1.0, 1), (90, 1.0, 0), (77, 0.12, 1), (96, 0.1, 0)])
+def test_mid_width_register_resident_passes_against_the_gram_tiles_and_the_oracle(kind, D, ell_factor, precision):
+    """32 < D <= 96: the register-resident mat-vec and gradient pass (padded widths 48, 64, 80, 96; the last with a row shared by four
+    lanes in the gradient pass) against the same context run through the Gram tiles (wide_reg = 0) and against the dense oracle; ragged N
+    (not a multiple of the 64 / 128-row blocks), both precision levels, and short lengthscales that select the range-clamped variants."""
+    from cglb_amd.hip_context import HipContext
+    N, M = 1867, 40
+    X, y, Z, hyp = _problem(N, D, M, seed=D, ell_factor=ell_factor)
+    cov = orc.dense_cov(kind, X, hyp)
+    p = np.random.default_rng(5).standard_normal(N)
+    out = {}
+    for reg in (1, 0):
+        ctx = HipContext(X, y, M, kind)
+        ctx.set_option("wide_reg", reg)
+        ctx.set_option("precision", precision)
+        ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+        ctx.setup()
+        Ap = ctx.matvec(torch.from_numpy(p)).cpu().numpy()
+        v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
+        res = ctx.objective_and_grad(v, True, 1e-2, 100, 40)
+        out[reg] = (Ap, res, v.cpu().numpy())
+        ctx.close()
+    ref_mv = cov @ p
+    for reg in (1, 0):
+        np.testing.assert_allclose(out[reg][0], ref_mv, rtol=0, atol=1e-11 * np.abs(ref_mv).max())
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=2e-12 * np.abs(ref_mv).max())
+    # Each variant against the oracle AT ITS OWN v: the two solves differ by the rounding of their mat-vecs (1e-14), which a 37-step solve
+    # behind a 40-point preconditioner amplifies to a different v within the stopping tolerance (and, at larger N, to other step counts)
+    for reg in (1, 0):
+        res, vh = out[reg][1], out[reg][2]
+        refg = orc.objective(kind, X, y, hyp, vh, run_cg=False, with_grad=True, cov=cov)
+        assert res.bound == pytest.approx(refg.bound, rel=1e-10)
+        for key in ("lengthscales", "Z", "variance", "noise", "mean"):
+            a, b = np.asarray(res.grad[key]), np.asarray(refg.grad[key])
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-9 * max(np.abs(b).max(), 1e-3 * abs(refg.bound)), err_msg=f"{key} (wide_reg {reg})")
 
 def test_wide_inducing_point_selection_and_backend_training_step():
     """Greedy conditional-variance selection and three L-BFGS-B iterations through the backend mirror at D = 50."""
