@@ -37,6 +37,9 @@ typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane
 #endif
 // minimum waves per SIMD asked of the compiler for the fp64 instances (padded width DP, R rows per lane); 1 = no constraint
 #define CGLB_SYM_WAVES(DP, R) (((DP) <= 8 && (R) <= 4) ? 3 : ((DP) == 32 ? 4 : ((DP) == 96 ? CGLB_SYM_WAVES_96 : 1)))
+#ifndef CGLB_SYM_BCAST_DP
+#define CGLB_SYM_BCAST_DP 33   // narrowest padded width (fp64) whose column operands travel in VGPRs and reach the fma by row_newbcast (below)
+#endif
 #ifndef CGLB_SYM_WAVES_96
 #define CGLB_SYM_WAVES_96 2
 #endif
@@ -68,11 +71,12 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
     // column operands therefore travel in VGPRs: slice s of a column is ONE register pair, lane l holding coordinate 16 s + l % 16 (a vector
     // load of 128 bytes), and the fma takes coordinate k from lane k of its 16-lane row (devmath.h: fmac_bcast).  Vector loads return in
     // order, so the compiler's vmcnt waits for the look-ahead are exact.
-    constexpr bool MID = DP > 32;
-    constexpr int CH = 16, NCH = MID ? DP / CH : 1, DJ = MID ? 1 : DP;
-    constexpr bool MID2 = MID && DP > 80;   // one wave per SIMD (VGPR budget): two interleaved chains instead of one
-    static_assert(!MID || (R == 1 && sizeof(T) == 8 && DP % CH == 0), "mid-width instances: fp64, one row per lane, width a multiple of 16");
-    const int l16 = lane & 15;
+    constexpr bool MID = sizeof(T) == 8 && DP >= CGLB_SYM_BCAST_DP;
+    constexpr int CH = !MID ? 16 : (DP % 16 == 0 ? 16 : (DP % 8 == 0 ? 8 : 4));   // coordinates per slice register (a divisor of DP)
+    constexpr int NCH = MID ? DP / CH : 1, DJ = MID ? 1 : DP;
+    constexpr bool MID2 = MID && DP > 80;   // two interleaved chains instead of one
+    static_assert(!MID || (R == 1 && DP % CH == 0), "broadcast-operand instances: fp64, one row per lane");
+    const int l16 = lane & (CH - 1);
     constexpr int RP = PACKED ? R / 2 : 1;
     constexpr int RU = PACKED ? 1 : R;  // the unpacked row operands exist only on the other path
     T xi[RU][DP], ai[R], pr[R], acc[R];
