@@ -283,9 +283,10 @@ __global__ __launch_bounds__(256, 2) void grad_kff_mid_kernel(const double* __re
                 const T vj = vc[jc];
                 const T wu = (jc >= sym_from) ? uc[jc] : T(0);
                 const T aj = FOLD ? T(0) : ah[jc];
-                T g = aseed;
+                T g = aseed, g1 = T(0);   // two interleaved chains: the dependent-issue latency of one (~9 cycles) is not covered by two waves
 #pragma unroll
-                for (int sl = 0; sl < NCH; ++sl) BcastChain<0, CH>::run(g, xsl[sl], &xi[sl * CH]);
+                for (int sl = 0; sl < NCH; ++sl) BcastChain2<0, CH>::run(g, g1, xsl[sl], &xi[sl * CH]);
+                g += g1;
                 if constexpr (SPLIT == 4) g = sum_row_pairs(g);
                 g = sum_halves(g);
                 const T earg[1] = {(KIND == CGLB_RBF) ? (FOLD ? g : g + aj) : sqrt_hot<PREC, BIASED>(tfma<T>(T(-2), g, aj))};

@@ -49,6 +49,12 @@ typedef float sym_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane
 #ifndef CGLB_SYM_LATE_DP
 #define CGLB_SYM_LATE_DP 24  // padded row width from which the column operands are fetched after the Gram chain (below)
 #endif
+// column sums of a batch: in-register transpose-reduce (true) or through the LDS scratch (false).  One row per lane took the register form
+// because those instances ran 4 waves per SIMD; the broadcast-operand instances (2-3 waves) have the LDS to spare (CGLB_SYM_MID_TR_REG=1: A/B).
+#ifndef CGLB_SYM_MID_TR_REG
+#define CGLB_SYM_MID_TR_REG 0
+#endif
+#define SYM_TR_IN_REG(T, DP, R) (CGLB_SYM_TR_REG || ((R) == 1 && !(sizeof(T) == 8 && (DP) >= CGLB_SYM_BCAST_DP && !CGLB_SYM_MID_TR_REG)))
 #define SYM_TR_LD 65         // leading dimension of the 8 x 64 transposition scratch of a wave (odd: the column reads spread over the banks)
 
 // One work item: rows of block `rb` against the columns of chunk `k` that lie at or right of the block's first row.  Row sums go to
@@ -74,7 +80,10 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
     constexpr bool MID = sizeof(T) == 8 && DP >= CGLB_SYM_BCAST_DP;
     constexpr int CH = !MID ? 16 : (DP % 16 == 0 ? 16 : (DP % 8 == 0 ? 8 : 4));   // coordinates per slice register (a divisor of DP)
     constexpr int NCH = MID ? DP / CH : 1, DJ = MID ? 1 : DP;
-    constexpr bool MID2 = MID && DP > 80;   // two interleaved chains instead of one
+#ifndef CGLB_SYM_MID_CHAINS2_DP
+#define CGLB_SYM_MID_CHAINS2_DP 33
+#endif
+    constexpr bool MID2 = MID && DP >= CGLB_SYM_MID_CHAINS2_DP;   // two interleaved chains instead of one dependent chain
     static_assert(!MID || (R == 1 && DP % CH == 0), "broadcast-operand instances: fp64, one row per lane");
     const int l16 = lane & (CH - 1);
     constexpr int RP = PACKED ? R / 2 : 1;
@@ -246,7 +255,7 @@ __device__ __forceinline__ void kff_sym_item(const T* __restrict__ Xs, const T* 
         }
         if (jb >= sym_from) {  // wave-uniform
             // Column sums of the batch = sums ACROSS the 64 lanes of t[0..15].
-            if constexpr (R == 1 || CGLB_SYM_TR_REG) {
+            if constexpr (SYM_TR_IN_REG(T, DP, R)) {
                 // R == 1 (D > 16): the in-register transpose-reduce of round 1 (4 select/shuffle/add stages that halve the number of live
                 // vectors, then two butterfly adds) - those instances run 4 waves per SIMD, which the LDS scratch of the other form would
                 // cut to 3 (D = 24: 2.57 -> 2.91 ms).  Also for A/B builds (EXTRA_DEFS=-DCGLB_SYM_TR_REG=1).
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : CGLB_SYM_WAVES(DP, R))) 
                                                       T* __restrict__ Pcol, const double* __restrict__ exp_tab, T bias) {
     __shared__ double tab[CGLB_TAB_SIZE];
     __shared__ T csum[4 * SYM_CHUNK_MAX];
-    __shared__ T trbuf[(R == 1 || CGLB_SYM_TR_REG) ? 1 : 4 * 8 * SYM_TR_LD];  // transposition scratch of the four waves (unused for R == 1)
+    __shared__ T trbuf[SYM_TR_IN_REG(T, DP, R) ? 1 : 4 * 8 * SYM_TR_LD];  // transposition scratch of the four waves (unused for R == 1)
     load_exp_table(tab, exp_tab);  // before the early exit below: every thread reaches the barrier inside
     constexpr bool FOLD = (KIND == CGLB_RBF) && !CLAMP;
     const T* __restrict__ pc = FOLD ? pw : p;  // column-side operand
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : CGLB_SYM_WAVES(DP, R))) 
     if (__builtin_amdgcn_readfirstlane(it.x) >= 0) {
         const int64_t rb = __builtin_amdgcn_readfirstlane(it.x), k = __builtin_amdgcn_readfirstlane(it.y);
         const int64_t cslot = rb / rb_stride;  // compact slot: with a cyclic rank distribution only every rb_stride-th block is here
-        kff_sym_item<T, KIND, DP, R, CLAMP, PREC>(Xs, xa, p, pc, row0, n, chunk, rb, k, cslot, prow_ld, Prow, cs, trbuf + ((R == 1 || CGLB_SYM_TR_REG) ? 0 : wave * 8 * SYM_TR_LD), tab, lane, bias);
+        kff_sym_item<T, KIND, DP, R, CLAMP, PREC>(Xs, xa, p, pc, row0, n, chunk, rb, k, cslot, prow_ld, Prow, cs, trbuf + (SYM_TR_IN_REG(T, DP, R) ? 0 : wave * 8 * SYM_TR_LD), tab, lane, bias);
     }
     __syncthreads();
     const int64_t gslot = __builtin_amdgcn_readfirstlane(grp.x), k = __builtin_amdgcn_readfirstlane(grp.y);
