@@ -242,20 +242,28 @@ __global__ __launch_bounds__(256, 2) void grad_kff_mid_kernel(const double* __re
     __shared__ double smem[16];
     __shared__ double tab[CGLB_TAB_SIZE];
     __shared__ T trbuf[4 * 8 * GRAD_TR_LD];
+    // DP = 96 with a row shared by two lanes needs 265 registers with the second-moment accumulators in VGPRs - one wave per SIMD; kept in
+    // LDS instead (a private column of 12 slots per lane: no conflicts, no barrier; 36 LDS operations per batch of 8 columns) it fits 2 waves
+    constexpr bool G2LDS = (DP > 80 && SPLIT == 2);
+    __shared__ T g2buf[G2LDS ? 4 * NQ * 64 : 1];
     load_exp_table(tab, exp_tab);
     const int lane = threadIdx.x & 63, prt = lane / WROWS, l8 = lane & 7;   // prt: which 1 / SPLIT of the dimensions this lane holds
+    T* __restrict__ g2 = g2buf + (G2LDS ? (threadIdx.x >> 6) * (NQ * 64) + lane : 0);
     T* __restrict__ tr = trbuf + (threadIdx.x >> 6) * (8 * GRAD_TR_LD);
     const int64_t rblock = ((int64_t)blockIdx.x * rb_stride + rb_offset) * (4 * WROWS);
     const int64_t row = rblock + (threadIdx.x >> 6) * WROWS + (lane & (WROWS - 1));
     const int64_t rr = row < n ? row : n - 1;
-    T xi[HD], S1[HD], G2[NQ];
+    T xi[HD], S1[HD], G2[G2LDS ? 1 : NQ];
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
         xi[d] = Xh[rr * DP + prt * HD + d];
         S1[d] = 0;
     }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) G2[q] = 0;
+    for (int q = 0; q < NQ; ++q) {
+        if constexpr (G2LDS) g2[q * 64] = 0;
+        else G2[q] = 0;
+    }
     T S0 = 0;
     const T a = ah[rr];
     const T aseed = prt ? T(0) : ((KIND == CGLB_RBF) ? a : (BIASED ? T(-0.5) * (a + bias) : T(-0.5) * a));  // the seed enters the sum of the parts once
@@ -324,13 +332,14 @@ __global__ __launch_bounds__(256, 2) void grad_kff_mid_kernel(const double* __re
             const int d = (lane >> 3) + 8 * q;
             if (d < DP) {
                 const T x = xq[d];
-                G2[q] = tfma<T>(cs, x * x, G2[q]);
+                if constexpr (G2LDS) g2[q * 64] = tfma<T>(cs, x * x, g2[q * 64]);
+                else G2[q] = tfma<T>(cs, x * x, G2[q]);
             }
         }
     }
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
-        double s = ((lane >> 3) == (d & 7)) ? G2[d >> 3] : 0.0;
+        double s = ((lane >> 3) == (d & 7)) ? (G2LDS ? g2[(d >> 3) * 64] : G2[G2LDS ? 0 : (d >> 3)]) : 0.0;
         const int dl = d % HD;     // the part that holds dimension d adds the row terms
         if (prt == d / HD) s += xi[dl] * (xi[dl] * S0 - 2.0 * S1[dl]);
         s = block_sum(s, smem);
@@ -425,11 +434,18 @@ static int grad_fold_operands(cglb_ctx* c, const void* v_full, const void* u, in
     return CGLB_OK;
 }
 
+// Lanes sharing a matrix row at padded width 96: 2 with the second moments in LDS (16.8 ms at N = 50k; 24.7 with 4).  The Matern-3/2
+// instance of the exact level (two-step square root) does not fit 256 registers that way (101 spilled: 41 ms) and keeps 4 (25.5 ms).
+static inline int grad_mid_split(const cglb_ctx* c) {
+    if (c->Dh != 96) return 2;
+    return (c->kind != CGLB_RBF && c->precision == CGLB_PREC_EXACT) ? 4 : 2;
+}
 // Mid-width contexts: the whole symmetric form register-resident (rb_stride / rb_offset: the cyclic deal of the 128-row blocks)
 static int launch_grad_kff_mid(cglb_ctx* c, const void* v_full, const void* u_full, int world, int rank, double* out_dl) {
     bool fold = false;
     CGLB_TRY(grad_fold_operands(c, v_full, u_full, 0, c->N, &fold));
-    const int brows = c->Dh == 96 ? 64 : 128;   // rows of a workgroup: 256 / SPLIT
+    const int split = grad_mid_split(c);
+    const int brows = 256 / split;   // rows of a workgroup
     const int64_t nb = (c->N + brows - 1) / brows;
     const int64_t bx = rank < nb ? (nb - rank + world - 1) / world : 0;
     if (bx == 0) {
@@ -446,8 +462,9 @@ static int launch_grad_kff_mid(cglb_ctx* c, const void* v_full, const void* u_fu
     CGLB_TRY(ensure_gpart(c, (size_t)nblk * c->Dh * sizeof(double)));
     dim3 grid((unsigned)bx, (unsigned)jsplit);
     const bool lowprec = c->precision != CGLB_PREC_EXACT;   // level 2 runs as level 1 here
-#define GM_LAUNCH1(DPV, PR, CL)                                                                                                                        \
-    hipLaunchKernelGGL((grad_kff_mid_kernel<KIND, DPV, PR, CL, (DPV == 96 ? 4 : 2)>), grid, dim3(256), 0, c->stream, (const double*)c->Xh, (const double*)c->xah,         \
+#define GM_LAUNCH1(DPV, PR, CL) do { if (DPV == 96 && split == 4) { GM_LAUNCH0(DPV, PR, CL, (DPV == 96 ? 4 : 2)); } else { GM_LAUNCH0(DPV, PR, CL, 2); } } while (0)
+#define GM_LAUNCH0(DPV, PR, CL, SP)                                                                                                                    \
+    hipLaunchKernelGGL((grad_kff_mid_kernel<KIND, DPV, PR, CL, SP>), grid, dim3(256), 0, c->stream, (const double*)c->Xh, (const double*)c->xah,         \
                        (const double*)u_full, (const double*)v_full, (CL || !fold) ? (const double*)u_full : (const double*)c->uwh,                    \
                        (CL || !fold) ? (const double*)v_full : (const double*)c->pwh, c->N, jchunk, world, rank, c->gpart, (const double*)c->exp_tab, \
                        c->m32_bias)
@@ -464,6 +481,7 @@ static int launch_grad_kff_mid(cglb_ctx* c, const void* v_full, const void* u_fu
     });
 #undef GM_LAUNCH
 #undef GM_LAUNCH1
+#undef GM_LAUNCH0
     CGLB_LAUNCH_CHECK(c);
     const double hot = cglb_hot_scale(c);
     hipLaunchKernelGGL(grad_dl_finalize_mid_kernel, dim3(c->D), dim3(256), 0, c->stream, (const double*)c->gpart, nblk, c->Dh, c->D, (const double*)c->wsmall,
