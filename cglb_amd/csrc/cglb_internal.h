@@ -76,6 +76,8 @@ struct cglb_ctx {
     void *Xsq = nullptr, *Zsq = nullptr;
     void *wtile = nullptr, *wpart = nullptr, *wS1 = nullptr, *wVX = nullptr, *wR = nullptr, *wC = nullptr, *wones = nullptr, *wpanel = nullptr;
     size_t wtile_cap = 0, wpart_cap = 0, wS1_cap = 0, wpanel_cap = 0, wvec_cap = 0;
+    void* wlong = nullptr;   // slabs of a long-k GEMM cut into chunks (kernels_wide.hip: gemm_long_k)
+    size_t wlong_cap = 0;
     double *wcenter = nullptr, *wscale = nullptr, *wsmall = nullptr;
     void* uwh = nullptr;                 // u o wh: second weighted column operand of the Gram-form gradient pass (allocated on first use)
     void *wh = nullptr, *pwh = nullptr;  // RBF column weights 2^(xah_j/T) and the weighted operand p_j * wh_j of the symmetric mat-vec (length N)

@@ -32,6 +32,16 @@ inline rocblas_status wgemm(rocblas_handle h, rocblas_operation ta, rocblas_oper
     const float a = (float)al, b = (float)be;
     return rocblas_sgemm(h, ta, tb, m, n, k, &a, A, lda, B, ldb, &b, C, ldc);
 }
+inline rocblas_status wgemm_sb(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double* A, int lda, rocblas_stride sa,
+                               const double* B, int ldb, rocblas_stride sb, double* C, int ldc, rocblas_stride sc, int batch) {
+    const double one = 1.0, zero = 0.0;
+    return rocblas_dgemm_strided_batched(h, ta, tb, m, n, k, &one, A, lda, sa, B, ldb, sb, &zero, C, ldc, sc, batch);
+}
+inline rocblas_status wgemm_sb(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const float* A, int lda, rocblas_stride sa,
+                               const float* B, int ldb, rocblas_stride sb, float* C, int ldc, rocblas_stride sc, int batch) {
+    const float one = 1.0f, zero = 0.0f;
+    return rocblas_sgemm_strided_batched(h, ta, tb, m, n, k, &one, A, lda, sa, B, ldb, sb, &zero, C, ldc, sc, batch);
+}
 inline rocblas_status wgemv(rocblas_handle h, rocblas_operation t, int m, int n, double al, const double* A, int lda, const double* x, double be, double* y) {
     return rocblas_dgemv(h, t, m, n, &al, A, lda, x, 1, &be, y, 1);
 }
@@ -341,7 +351,7 @@ int matvec_impl(cglb_ctx* c, const T* XsRow, const T* xaRow, int64_t row0_global
 
 // =========================================================== launchers ===========================================================
 void wide_free(cglb_ctx* c) {
-    void* ptrs[] = {c->Xsq, c->Zsq, c->wtile, c->wpart, c->wS1, c->wVX, c->wR, c->wC, c->wones, c->wpanel, c->wcenter, c->wscale, c->wsmall};
+    void* ptrs[] = {c->wlong, c->Xsq, c->Zsq, c->wtile, c->wpart, c->wS1, c->wVX, c->wR, c->wC, c->wones, c->wpanel, c->wcenter, c->wscale, c->wsmall};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
 
@@ -470,6 +480,43 @@ int wide_grad_kff(cglb_ctx* c, const void* v_full_, const void* u_rows_, int64_t
     return CGLB_OK;
 }
 
+// out[i] = sum_b slabs[b * count + i] in fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void wide_slab_sum_kernel(const T* __restrict__ slabs, int nb, int64_t count, T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    T s = 0;
+    for (int b = 0; b < nb; ++b) s += slabs[(int64_t)b * count + i];
+    out[i] = s;
+}
+
+// C (m x n, ld m) = A (m x k, lda) B (k x n, ldb) for a contraction far longer than the output is wide (k = N against m n = D M): one
+// rocBLAS GEMM of that shape keeps a handful of workgroups busy (measured 5.4 ms for 7.9 GFLOP at N = 50 000, D = 77, M = 1024).  The
+// contraction is cut into chunks of 1024, one strided-batched GEMM writes a slab per chunk and the slabs are added in fixed order.
+template <typename T>
+int gemm_long_k(cglb_ctx* c, int m, int n, int64_t k, const T* A, int lda, const T* B, int ldb, T* C) {
+    const int64_t kc = 1024;
+    const int nfull = (int)(k / kc);
+    const int64_t rem = k - (int64_t)nfull * kc;
+    const int nb = nfull + (rem > 0 ? 1 : 0);
+    if (nb <= 1) {
+        BLAS_CHECK(c, wgemm(c->blas, rocblas_operation_none, rocblas_operation_none, m, n, (int)k, 1.0, A, lda, B, ldb, 0.0, C, m));
+        return CGLB_OK;
+    }
+    const int64_t count = (int64_t)m * n;
+    CGLB_TRY(wensure(c, &c->wlong, &c->wlong_cap, (size_t)nb * count * sizeof(T)));
+    T* slabs = (T*)c->wlong;
+    if (nfull > 0)
+        BLAS_CHECK(c, wgemm_sb(c->blas, rocblas_operation_none, rocblas_operation_none, m, n, (int)kc, A, lda, (rocblas_stride)(kc * lda), B, ldb, (rocblas_stride)kc,
+                               slabs, m, (rocblas_stride)count, nfull));
+    if (rem > 0)
+        BLAS_CHECK(c, wgemm(c->blas, rocblas_operation_none, rocblas_operation_none, m, n, (int)rem, 1.0, A + (int64_t)nfull * kc * lda, lda, B + (int64_t)nfull * kc, ldb,
+                            0.0, slabs + (int64_t)nfull * count, m));
+    hipLaunchKernelGGL((wide_slab_sum_kernel<T>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, (const T*)slabs, nb, count, C);
+    CGLB_LAUNCH_CHECK(c);
+    return CGLB_OK;
+}
+
 // Packed-gradient contributions of an adjoint panel G (row m contiguous, ld = ldg; + optional rank-1 term cvec[m] wvec[n]) of
 // K(z_m, col_n): same contract as grad_panel (kernels_grad.hip).  XsCol / xaCol / XsqCol: scaled operands of the ncols columns.
 int wide_grad_panel(cglb_ctx* c, const void* G, int64_t ldg, const void* cvec, const void* wvec, const void* XsCol, const void* xaCol, const void* XsqCol,
@@ -492,7 +539,7 @@ int wide_grad_panel(cglb_ctx* c, const void* G, int64_t ldg, const void* cvec, c
         // R_m = sum_n W_mn, C_n = sum_m W_mn, T_md = sum_n W_mn xs_nd
         BLAS_CHECK(c, wgemv(c->blas, rocblas_operation_transpose, (int)ncols, M, 1.0, (const T*)S, (int)ld, (const T*)c->wones, 0.0, R));
         BLAS_CHECK(c, wgemv(c->blas, rocblas_operation_none, (int)ncols, M, 1.0, (const T*)S, (int)ld, (const T*)c->wones, 0.0, C));
-        BLAS_CHECK(c, wgemm(c->blas, rocblas_operation_none, rocblas_operation_none, D, M, (int)ncols, 1.0, (const T*)XsCol, D, (const T*)S, (int)ld, 0.0, Tm, D));
+        CGLB_TRY((gemm_long_k<T>(c, D, M, ncols, (const T*)XsCol, D, (const T*)S, (int)ld, Tm)));
         double* xc = c->wsmall + 2 * (size_t)D;   // xc_d = sum_n xs_nd^2 C_n
         hipLaunchKernelGGL((wide_coldot_kernel<T>), dim3(D), dim3(256), 0, c->stream, (const T*)XsqCol, (const T*)nullptr, (const T*)C, ncols, D, xc);
         const int zblocks = (int)(((int64_t)M * D + 255) / 256);
