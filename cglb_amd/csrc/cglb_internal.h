@@ -236,6 +236,9 @@ int launch_frag_prep(cglb_ctx* c);
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot);
 int launch_hot_weights(cglb_ctx* c);
 int launch_kff_sym_mid(cglb_ctx* c, const void* p_full, void* out, double* pdot_slot, bool cyclic);  // 32 < D <= 96, fp64 (kernels_kff_sym.hip)
+int ensure_gpart(cglb_ctx* c, size_t need);   // partial-sum slab of the gradient passes (kernels_grad.hip)
+int grad_fold_operands(cglb_ctx* c, const void* v_full, const void* u, int64_t off, int64_t n_u, bool* fold);  // column-side copies u o w, v o w (folded column norm)
+int launch_grad_kff_mid(cglb_ctx* c, const void* v_full, const void* u_full, int world, int rank, double* out_dl);  // kernels_grad_mid.hip
 int launch_hot_squares(cglb_ctx* c);  // Xhsq = Xh .* Xh after set_hypers
 int k1_profile_collect(cglb_ctx* c);  // resolves the pending event pairs into k1_ms_total / k1_launches  // wh = 2^(xah/T) after set_hypers (RBF)
 int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partial);  // this rank's share of the global upper triangle

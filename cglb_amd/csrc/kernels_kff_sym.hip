@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256) void weight_operand_kernel(const T* __restrict
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) pw[i] = p[i] * wh[i];
 }
+#ifndef CGLB_SYM_MID_TU
 int launch_hot_weights(cglb_ctx* c) {
     if (c->kind != CGLB_RBF || (is_wide(c) && c->Dh == 0)) return CGLB_OK;
     const int grid = (int)((c->N + 255) / 256);
@@ -467,7 +468,9 @@ int launch_hot_weights(cglb_ctx* c) {
     return CGLB_OK;
 }
 
-__global__ __launch_bounds__(256) void finalize_sum_sym_kernel(const double* __restrict__ partials, int n, double* __restrict__ out) {
+#endif  // !CGLB_SYM_MID_TU
+
+static __global__ __launch_bounds__(256) void finalize_sum_sym_kernel(const double* __restrict__ partials, int n, double* __restrict__ out) {
     __shared__ double smem[16];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) s += partials[i];
@@ -670,6 +673,7 @@ static int kff_sym_generic(cglb_ctx* c, const T* p_full, T* out_local, double* p
     return CGLB_OK;
 }
 
+#ifndef CGLB_SYM_MID_TU
 int k1_profile_collect(cglb_ctx* c) {
     for (size_t q = 0; q + 1 < c->k1_events_used; q += 2) {
         HIP_CHECK(c, hipEventSynchronize(c->k1_events[q + 1]));
@@ -682,7 +686,12 @@ int k1_profile_collect(cglb_ctx* c) {
     return CGLB_OK;
 }
 
-// mid-width contexts (cglb_internal.h: mid_dim): the same kernel on the Dh-wide hot operand set, Gram chain in slices
+#endif  // !CGLB_SYM_MID_TU
+
+#ifdef CGLB_SYM_MID_TU
+// mid-width contexts (cglb_internal.h: mid_dim): the same kernel on the Dh-wide hot operand set, Gram chain in slices.  These instances
+// are compiled in their own translation unit (kernels_kff_sym_mid.hip includes this file with CGLB_SYM_MID_TU defined), in parallel
+// with the narrow ones.
 #define CGLB_DISPATCH_DH(dh, ...)                                           \
     switch (dh) {                                                           \
         case 48: { constexpr int DP = 48; __VA_ARGS__; } break;             \
@@ -699,6 +708,7 @@ int launch_kff_sym_mid(cglb_ctx* c, const void* p_full, void* out, double* pdot_
     return CGLB_OK;
 }
 
+#else   // the narrow translation unit
 int launch_kff_sym(cglb_ctx* c, const void* p_full, void* out_local, double* pdot_slot) {
     if (is_wide(c)) return launch_kff_matvec(c, p_full, out_local, pdot_slot);
     CGLB_DISPATCH_ALL(c, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out_local, pdot_slot, false)));
@@ -712,3 +722,4 @@ int launch_kff_sym_cyclic(cglb_ctx* c, const void* p_full, void* out_full_partia
     CGLB_DISPATCH_ALL(c, return (kff_sym_generic<T, KIND, DP>(c, (const T*)p_full, (T*)out_full_partial, nullptr, true)));
     return CGLB_OK;
 }
+#endif  // CGLB_SYM_MID_TU
