@@ -102,6 +102,35 @@ def test_mid_width_register_resident_passes_against_the_gram_tiles_and_the_oracl
             a, b = np.asarray(res.grad[key]), np.asarray(refg.grad[key])
             np.testing.assert_allclose(a, b, rtol=0, atol=1e-9 * max(np.abs(b).max(), 1e-3 * abs(refg.bound)), err_msg=f"{key} (wide_reg {reg})")
 
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+@pytest.mark.parametrize("N,D,M", [(1, 40, 1), (2, 90, 2), (63, 64, 5), (64, 77, 64), (65, 90, 7), (129, 40, 16), (257, 96, 9)])
+def test_mid_width_edge_shapes(kind, N, D, M):
+    """Fewer rows than a 64-row block, exactly one block, one row beyond a block boundary (64-row blocks of the mat-vec, 128-row blocks
+    of the gradient pass), N = 1, M = N: every shape against the dense oracle."""
+    from cglb_amd.hip_context import HipContext
+    X, y, Z = orc.synthetic_problem(max(N, M, 8), D, M, seed=N + D)
+    X, y = X[:N], y[:N]
+    rng = np.random.default_rng(N)
+    hyp = orc.Hypers(rng.uniform(0.8, 1.6, size=D) * np.sqrt(D), 1.3, 0.08, 0.15, Z, 1e-6)
+    ctx = HipContext(X, y, M, kind)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+    ctx.setup()
+    cov = orc.dense_cov(kind, X, hyp)
+    p = rng.standard_normal(N)
+    Ap = ctx.matvec(torch.from_numpy(p)).cpu().numpy()
+    np.testing.assert_allclose(Ap, cov @ p, rtol=0, atol=1e-12 * np.abs(cov @ p).max())
+    v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
+    res = ctx.objective_and_grad(v, True, 1e-2, 100, 40)
+    ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, 1e-2, 100, 40, cov=cov)
+    assert res.steps == ref.steps
+    refg = orc.objective(kind, X, y, hyp, v.cpu().numpy(), run_cg=False, with_grad=True, cov=cov)
+    assert res.bound == pytest.approx(refg.bound, rel=1e-10, abs=1e-10)
+    for key in ("lengthscales", "Z", "variance", "noise", "mean"):
+        a, b = np.asarray(res.grad[key]), np.asarray(refg.grad[key])
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-8 * max(np.abs(b).max(), 1e-3 * abs(refg.bound), 1e-6), err_msg=key)
+    ctx.close()
+
+
 def test_wide_inducing_point_selection_and_backend_training_step():
     """Greedy conditional-variance selection and three L-BFGS-B iterations through the backend mirror at D = 50."""
     from cglb_amd.backend import BACKENDS, CGLBConfig, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS
@@ -134,14 +163,14 @@ def _free_port():
     return port
 
 
-def _dist_worker(rank, world, port, q):
+def _dist_worker(rank, world, port, q, shape=(9000, 40, 128)):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cglb_amd.dist_context import DistHipContext
-        N, D, M = 9000, 40, 128      # three 4096-row tiles: dealt 2 + 1 over the two ranks; 22 CG steps
+        N, D, M = shape              # (9000, 40, 128): three 4096-row tiles, 22 CG steps
         X, y, Z, hyp = _problem(N, D, M, seed=3)
         ctx = DistHipContext(X, y, M, "rbf", collectives="callbacks")
         ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
@@ -175,3 +204,32 @@ def test_wide_inputs_on_two_ranks():
         np.testing.assert_allclose(grad["lengthscales"], refg.grad["lengthscales"], rtol=0, atol=1e-7 * np.abs(refg.grad["lengthscales"]).max())
         np.testing.assert_allclose(grad["Z"], refg.grad["Z"], rtol=0, atol=1e-7 * np.abs(refg.grad["Z"]).max())
     assert out[0][1:3] == out[1][1:3]
+
+
+
+def test_mid_width_on_three_ranks_with_uneven_block_shares():
+    """N = 300 at D = 77: five 64-row blocks of the mat-vec and three 128-row blocks of the gradient pass dealt over three ranks (2 + 2 + 1
+    and 1 + 1 + 1), loops and collectives inside the library (callbacks over gloo, all ranks on cuda:0)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    shape = (300, 77, 24)
+    procs = [ctx.Process(target=_dist_worker, args=(r, 3, port, q, shape)) for r in range(3)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=600) for _ in range(3)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    N, D, M = shape
+    X, y, Z, hyp = _problem(N, D, M, seed=3)
+    cov = orc.dense_cov("rbf", X, hyp)
+    ref = orc.objective("rbf", X, y, hyp, np.zeros(N), True, 1.0, 100, 40, cov=cov)
+    for rank, steps, bound, v, grad in out:
+        assert steps == ref.steps, rank
+        refg = orc.objective("rbf", X, y, hyp, v, run_cg=False, with_grad=True, cov=cov)
+        assert bound == pytest.approx(refg.bound, rel=1e-10)
+        for key in ("lengthscales", "Z", "variance", "noise"):
+            b = np.asarray(refg.grad[key])
+            np.testing.assert_allclose(np.asarray(grad[key]), b, rtol=0, atol=1e-8 * max(np.abs(b).max(), 1e-3 * abs(refg.bound)), err_msg=key)
+    assert out[0][1:3] == out[1][1:3] == out[2][1:3]
