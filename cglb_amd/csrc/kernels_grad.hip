@@ -18,6 +18,7 @@
 //   SYM = true : the square block rows x rows.  The form is symmetric under i <-> j, so only columns at or beyond the
 //                block's first row are visited: the diagonal 256R x 256R block in full with w = u_i v_j, everything to its
 //                right once with w = u_i v_j + u_j v_i  (halves the pair evaluations).
+typedef float gk_f2 __attribute__((ext_vector_type(2)));  // two rows of a lane side by side (fp32 path of grad_kff_kernel)
 template <typename T, int KIND, int DP, int R, bool SYM, int PREC>
 __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsRow, const T* __restrict__ uRow, const T* __restrict__ vRow,
                                                        int64_t nrows, const T* __restrict__ XsCol, const T* __restrict__ vCol,
@@ -29,6 +30,59 @@ __global__ __launch_bounds__(256) void grad_kff_kernel(const T* __restrict__ XsR
     load_exp_table(tab, exp_tab);
     const int64_t rblock = ((int64_t)blockIdx.x * rb_stride + rb_offset) * (256 * R);  // cyclic over ranks when rb_stride > 1
     const int64_t rbase = rblock + threadIdx.x;
+    if constexpr (sizeof(T) == 4 && R == 2) {
+        // fp32: the two rows of a lane side by side, so that differences, squares, the distance and the D accumulations run as v_pk_*_f32
+        // (4 packed instructions per dimension and row PAIR against 4 per dimension and row); the column operand is broadcast to both halves
+        // from its SGPR.  The pair weight (hardware exp2) stays per row.  Measured at N = 400 000: D = 16 101.2 -> 90.9 ms, D = 8 56.0 -> 49.8 ms;
+        // padded width 28 loses (42.4 -> 48.4 ms at N = 200 000: registers), so wider rows keep one row per lane.
+        gk_f2 xi2[DP], acc2[DP];
+        float ui2[2], vi2[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t row = rbase + (int64_t)k * 256;
+            const int64_t rr = row < nrows ? row : nrows - 1;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                xi2[d][k] = XsRow[rr * DP + d];
+                acc2[d][k] = 0.f;
+            }
+            ui2[k] = row < nrows ? uRow[rr] : 0.f;
+            vi2[k] = (SYM && row < nrows) ? vRow[rr] : 0.f;
+        }
+        int64_t j0 = (int64_t)blockIdx.y * jchunk;
+        const int64_t j1 = (j0 + jchunk < ncols) ? j0 + jchunk : ncols;
+        const int64_t sym_from = rblock + 256 * R;
+        if (SYM && j0 < rblock) j0 = rblock;
+        for (int64_t j = j0; j < j1; ++j) {
+            const float vj = vCol[j];
+            float wu = 0.f;
+            if (SYM) wu = (j >= sym_from) ? uCol[j] : 0.f;  // wave-uniform
+            gk_f2 sq[DP], d2 = {0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const float x = XsCol[j * DP + d];
+                const gk_f2 df = xi2[d] - gk_f2{x, x};
+                sq[d] = df * df;
+                d2 += sq[d];
+            }
+            gk_f2 hv;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float w = ui2[k] * vj;
+                if (SYM) w = __builtin_fmaf(vi2[k], wu, w);
+                hv[k] = hfac_hot_from_d2<float, KIND, true, PREC>(d2[k], tab) * w;
+            }
+#pragma unroll
+            for (int d = 0; d < DP; ++d) acc2[d] = __builtin_elementwise_fma(hv, sq[d], acc2[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            double s = (double)acc2[d][0] + (double)acc2[d][1];
+            s = block_sum(s, smem);
+            if (threadIdx.x == 0) part[(blk0 + (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * DP + d] = s;
+        }
+        return;
+    }
     T xi[R][DP], acc[R][DP], ui[R], vi[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -313,7 +367,7 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
     const bool use_gram = c->grad_gram && c->dtype == CGLB_F64;
     bool fold = false;
     if (use_gram) CGLB_TRY(grad_fold_operands(c, v_full, u_local, c->r0, c->nloc, &fold));
-    const int R = c->Dp <= 8 ? 2 : 1;
+    const int R = (c->Dp <= 8 || (c->dtype == CGLB_F32 && c->Dp <= 16)) ? 2 : 1;   // fp32 up to width 16: two rows per lane (packed arithmetic)
     const int Rg = CGLB_GRAM_ROWS_OF(c->Dp);  // the Gram-form kernel (square range only)
     // three column ranges: the square block (symmetric form) and the shard's off-diagonal ranges [0,r0), [r1,N)
     struct Range { int64_t col0, ncols; bool sym; int64_t jsplit, jchunk; } rg[3] = {
@@ -352,8 +406,8 @@ int launch_grad_kff(cglb_ctx* c, const void* v_full, const void* u_local, double
         if (r.sym && use_gram) {
             // u_local is indexed by global row inside the kernel (row0 + local), hence the shifted base pointer
             CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, GG_LAUNCH(CGLB_GRAM_ROWS_OF(DP))));
-        } else if (r.sym) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); })); }
-        else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); })); }
+        } else if (r.sym) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8 || (sizeof(T) == 4 && DP <= 16)) { GK_LAUNCH(2, true); } else { GK_LAUNCH(1, true); })); }
+        else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8 || (sizeof(T) == 4 && DP <= 16)) { GK_LAUNCH(2, false); } else { GK_LAUNCH(1, false); })); }
 #undef GG_LAUNCH
 #undef GG_LAUNCH1
 #undef GK_LAUNCH
@@ -380,7 +434,7 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
     const bool use_gram = c->grad_gram && c->dtype == CGLB_F64;
     bool fold = false;
     if (use_gram) CGLB_TRY(grad_fold_operands(c, v_full, u_full, 0, c->N, &fold));
-    const int R = use_gram ? CGLB_GRAM_ROWS_OF(c->Dp) : (c->Dp <= 8 ? 2 : 1);
+    const int R = use_gram ? CGLB_GRAM_ROWS_OF(c->Dp) : ((c->Dp <= 8 || (c->dtype == CGLB_F32 && c->Dp <= 16)) ? 2 : 1);
     const int64_t nb = (c->N + 256 * R - 1) / (256 * R);
     const int64_t bx = c->par_rank < nb ? (nb - c->par_rank + c->par_world - 1) / c->par_world : 0;
     if (bx == 0) {
@@ -407,7 +461,7 @@ int launch_grad_kff_cyclic(cglb_ctx* c, const void* v_full, const void* u_full, 
                        c->gpart, (const double*)c->exp_tab, (T)c->m32_bias)
 #define GGC_LAUNCH(RR) do { if (c->exp_clamp) { GGC_LAUNCH1(RR, true); } else { GGC_LAUNCH1(RR, false); } } while (0)
     if (use_gram) { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, GGC_LAUNCH(CGLB_GRAM_ROWS_OF(DP)))); }
-    else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); })); }
+    else { CGLB_DISPATCH_ALL(c, CGLB_DISPATCH_PREC(c, if constexpr (DP <= 8 || (sizeof(T) == 4 && DP <= 16)) { GKC_LAUNCH(2); } else { GKC_LAUNCH(1); })); }
 #undef GGC_LAUNCH
 #undef GGC_LAUNCH1
 #undef GKC_LAUNCH

@@ -96,7 +96,10 @@ def check_case(c, fp32=False, options=None):
         # single-precision assembly error.
         if not (res.residual_error <= tol * (1 + 1e-4) or res.steps == 100):
             why.append("not converged (fp32)")
-        if abs(res.bound - ref.bound) > 1.001 * tol + 1e-4 * abs(ref.bound):
+        # (a solve that ends at max_iter unconverged - both did on seed 5, draw N = 8473, M = 2 - leaves its upper within ITS OWN statistic
+        # of the exact value instead of within the tolerance)
+        slack = max(tol, res.residual_error, ref.residual_error)
+        if abs(res.bound - ref.bound) > 1.001 * slack + 1e-4 * abs(ref.bound):
             why.append("bound (fp32)")
     elif dsteps > 0 or not e_b < 1e-6:
         # probe amplitude: the documented kernel-value accuracy of the level, raised until the probes' mat-vec deviates from the dense one
