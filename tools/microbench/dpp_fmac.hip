@@ -94,10 +94,11 @@ int main() {
     for (int w : {1, 2, 4}) {
         const float a8 = run(rate_kernel<0, 8>, cus, w), d8 = run(rate_kernel<1, 8>, cus, w);
         const float a1 = run(rate_kernel<0, 1>, cus, w), d1 = run(rate_kernel<1, 1>, cus, w);
+        const float a2 = run(rate_kernel<0, 2>, cus, w), d2 = run(rate_kernel<1, 2>, cus, w);
         const double n = (double)N_ITER * 96;
         const double clk = 2.4e9;  // nominal; the ratio is what matters
-        printf("%d wave(s) per SIMD: 8 chains: v_fma_f64 %.3f ms (%.2f nominal cycles per instruction), v_fmac_f64_dpp %.3f ms (%.2f); one dependent chain: %.3f ms (%.2f) / %.3f ms (%.2f)\n", w,
-               a8, a8 * 1e-3 * clk / n / w, d8, d8 * 1e-3 * clk / n / w, a1, a1 * 1e-3 * clk / n / w, d1, d1 * 1e-3 * clk / n / w);
+        printf("%d wave(s) per SIMD: 8 chains: v_fma_f64 %.3f ms (%.2f nominal cycles per instruction), v_fmac_f64_dpp %.3f ms (%.2f); one dependent chain: %.3f ms (%.2f) / %.3f ms (%.2f); two interleaved chains: %.3f ms (%.2f) / %.3f ms (%.2f)\n", w,
+               a8, a8 * 1e-3 * clk / n / w, d8, d8 * 1e-3 * clk / n / w, a1, a1 * 1e-3 * clk / n / w, d1, d1 * 1e-3 * clk / n / w, a2, a2 * 1e-3 * clk / n / w, d2, d2 * 1e-3 * clk / n / w);
     }
     return 0;
 }
