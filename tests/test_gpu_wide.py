@@ -131,6 +131,39 @@ def test_mid_width_edge_shapes(kind, N, D, M):
     ctx.close()
 
 
+def test_mid_width_low_precision_level_and_switching_the_path_on_one_context():
+    """precision 2 (kernel values to 1e-10) has its own mid-width mat-vec instances (the gradient pass runs level 1 there); and the option
+    wide_reg may be flipped on a live context - both paths serve the same operands."""
+    from cglb_amd.hip_context import HipContext
+    N, D, M = 1500, 77, 32
+    X, y, Z, hyp = _problem(N, D, M, seed=21)
+    cov = orc.dense_cov("rbf", X, hyp)
+    p = np.random.default_rng(3).standard_normal(N)
+    ctx = HipContext(X, y, M, "rbf")
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+    ctx.setup()
+    a1 = ctx.matvec(torch.from_numpy(p)).cpu().numpy()
+    ctx.set_option("wide_reg", 0)
+    a0 = ctx.matvec(torch.from_numpy(p)).cpu().numpy()
+    ctx.set_option("wide_reg", 1)
+    a1b = ctx.matvec(torch.from_numpy(p)).cpu().numpy()
+    ref = cov @ p
+    np.testing.assert_allclose(a1, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    np.testing.assert_allclose(a0, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    assert np.array_equal(a1, a1b)
+    ctx.set_option("precision", 2)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+    a2 = ctx.matvec(torch.from_numpy(p)).cpu().numpy()
+    err = np.abs(a2 - ref).max() / np.abs(ref).max()
+    assert 1e-13 < err < 2e-9, err     # the level-2 polynomial is really the one that ran, and it is as accurate as documented
+    v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
+    res = ctx.objective_and_grad(v, True, 1.0, 100, 40)
+    refg = orc.objective("rbf", X, y, hyp, v.cpu().numpy(), run_cg=False, with_grad=True, cov=cov)
+    assert res.bound == pytest.approx(refg.bound, rel=1e-6)
+    np.testing.assert_allclose(res.grad["lengthscales"], refg.grad["lengthscales"], rtol=0, atol=1e-6 * np.abs(refg.grad["lengthscales"]).max())
+    ctx.close()
+
+
 def test_wide_inducing_point_selection_and_backend_training_step():
     """Greedy conditional-variance selection and three L-BFGS-B iterations through the backend mirror at D = 50."""
     from cglb_amd.backend import BACKENDS, CGLBConfig, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS
