@@ -306,6 +306,27 @@ def main():
             del ctx_m, vm
         if not use_dist:
             secondary["training"] = training_secondary(X, y, Z, hypers[args.hypers], kind)
+        if not use_dist and (N, D, M, kind) == (100_000, 8, 1024, "rbf"):
+            # inputs of 33-96 dimensions (the wide Wilson sets: buzz 77, song 90): the two N^2 passes stay register-resident there
+            # (DESIGN.md section 4 "Mid widths"); one cold evaluation at N = 50 000, D = 77 for the record
+            Nw, Dw = 50_000, 77
+            Xw, yw, Zw = synthetic_problem(Nw, Dw, M, seed=0)
+            ctx_w = HipContext(Xw, yw, M, "rbf", device=dev)
+            lsw = np.full(Dw, 1.2 * np.sqrt(Dw))
+            ctx_w.set_hypers(lsw, 1.0, 0.05, 0.0, Zw, 1e-6)
+            vw = torch.zeros(Nw, dtype=torch.float64, device=dev)
+            resw = ctx_w.objective_and_grad(vw, True, cg["max_error"], cg["max_cg_iter"], cg["restart_cg_iter"], with_grad=True)
+            vw.zero_()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ctx_w.set_hypers(lsw, 1.0, 0.05, 0.0, Zw, 1e-6)
+            resw = ctx_w.objective_and_grad(vw, True, cg["max_error"], cg["max_cg_iter"], cg["restart_cg_iter"], with_grad=True)
+            torch.cuda.synchronize(dev)
+            dtw = time.perf_counter() - t0
+            secondary["mid_width"] = {"workload": f"N={Nw} D={Dw} M={M} rbf fp64, cold start", "value": 1.0 / dtw, "unit": "evals/s", "ms_per_step": dtw * 1e3,
+                                      "cg_steps": resw.steps, "bound": resw.bound, "kff_matvec_ms": ctx_w.time_kernel(0, 3), "grad_pass_ms": ctx_w.time_kernel(2, 2)}
+            ctx_w.close()
+            del ctx_w, vw, Xw, yw, Zw
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the library's stream -------------
     if driver == "native":

@@ -24,10 +24,13 @@ K_BOUND, K_GRAD = 4.0, 10.0
 KERNEL_DELTA = {0: 2.0 ** -52, 1: 1.0e-13}   # relative accuracy of the kernel values per precision level (include/cglb_hip.h "precision")
 
 
-def draw_case(rng, fp32=False, wide=False):
+def draw_case(rng, fp32=False, wide=False, large=False):
     """One draw of the sweep; consumes the generator in a fixed order so that (seed, index) names a case for good.
-    wide: D in [33, 120] (the GEMM-tiled path of kernels_wide.hip) instead of [1, 32]."""
+    wide: D in [33, 120] (kernels_wide.hip and the mid-width register-resident kernels) instead of [1, 32];
+    large: N in [9000, 24000] (several column chunks and dozens of row blocks per kernel; the dense oracle takes ~1 minute per case)."""
     N = int(rng.choice([rng.integers(2, 300), rng.integers(300, 3000), rng.integers(3000, 9000)]))
+    if large:
+        N = int(rng.integers(9000, 24000))
     D = int(rng.integers(33, 121)) if wide else int(rng.integers(1, 33))
     M = int(min(N, rng.choice([rng.integers(1, 70), rng.integers(60, 200), rng.integers(200, 700)])))
     kind = str(rng.choice(["rbf", "matern32"]))
@@ -167,11 +170,12 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     fp32 = len(sys.argv) > 3 and sys.argv[3] == "fp32"
-    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+    wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "widelarge")
+    large = len(sys.argv) > 3 and sys.argv[3] in ("large", "widelarge")
     bad = 0
     t0 = time.time()
     for _ in range(cases):
-        ok, line, _d = check_case(draw_case(rng, fp32, wide), fp32)
+        ok, line, _d = check_case(draw_case(rng, fp32, wide, large), fp32)
         bad += not ok
         print(line, flush=True)
     print(f"{cases} cases, {bad} bad, {time.time() - t0:.0f} s")
