@@ -887,6 +887,7 @@ int cglb_set_option(cglb_ctx* c, const char* name, int64_t value) {
     }
     else if (!strcmp(name, "drop_weighted_operand")) c->pwh_src = nullptr;  // the vector last written by cglb_vec_update_p_seg is about to change
     else if (!strcmp(name, "final_matvec")) c->final_matvec = (int)value;
+    else if (!strcmp(name, "wide_grad_sym")) c->wide_grad_sym = (int)value;
     else if (!strcmp(name, "wide_reg")) { c->wide_reg = (int)value; c->pwh_src = nullptr; }
     else if (!strcmp(name, "chol_mode")) c->chol_mode = (int)value;
     else if (!strcmp(name, "grad_trsm")) c->grad_trsm = (int)value;

@@ -44,6 +44,7 @@ struct cglb_ctx {
     int64_t N = 0, r0 = 0, r1 = 0, nloc = 0, lda = 0;  // lda: leading dimension of At/Guf (nloc rounded up to 8)
     int D = 0, Dp = 0, M = 0, dtype = CGLB_F64, kind = CGLB_RBF, device = 0;
     int Dh = 0;        // 32 < D <= 96, fp64: padded width (48, 64, 80, 96) of the hot operand set Xh kept for the register-resident mat-vec
+    int wide_grad_sym = 1;  // option "wide_grad_sym": 0 evaluates every tile of the tiled K_ff gradient pass (A/B)
     int wide_reg = 1;  // option "wide_reg": 0 sends that mat-vec through the Gram tiles of kernels_wide.hip as well (A/B, fallback)
     size_t esz = 8;
     hipStream_t stream = nullptr;

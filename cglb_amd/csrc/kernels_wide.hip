@@ -448,15 +448,30 @@ int wide_grad_kff(cglb_ctx* c, const void* v_full_, const void* u_rows_, int64_t
         HIP_CHECK(c, hipMemsetAsync(R, 0, (size_t)nrows * sizeof(T), c->stream));
         HIP_CHECK(c, hipMemsetAsync(C, 0, (size_t)N * sizeof(T), c->stream));
         hipLaunchKernelGGL((wide_rowscale_kernel<T>), dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, c->stream, (const T*)c->Xs, v, N, D, VX);
+        const bool sym = row0 == 0 && nrows == N && c->wide_grad_sym;
         int64_t t = 0;
         for (int64_t i0 = 0; i0 < nrows; i0 += TILE, ++t) {
             if (tile_stride > 1 && (t % tile_stride) != tile_offset) continue;
             const int64_t nr = std::min(TILE, nrows - i0);
-            for (int64_t j0 = 0; j0 < N; j0 += TILE) {
+            // The rows are all of X (one GPU, or the cyclic deal of the row tiles): H is symmetric, so a tile right of the diagonal also stands
+            // for its mirror image - its derivative factors are formed once and the three sums of the mirrored tile (R_J, C_I, T'_J) are
+            // taken from the same H with the operands swapped: half the Gram GEMMs and profile passes.
+            for (int64_t j0 = sym ? i0 : 0; j0 < N; j0 += TILE) {
                 const int64_t nc = std::min(TILE, N - j0);
                 CGLB_TRY(gram_tile<T>(c, (const T*)c->Xs + (row0 + i0) * D, nr, (const T*)c->Xs + j0 * D, nc, G, nr));
                 hipLaunchKernelGGL((wide_profile_kernel<T, KIND, 1>), dim3((unsigned)((nr + 255) / 256), (unsigned)nc), dim3(256), 0, c->stream, G, nr, nr, nc,
                                    (const T*)c->xa + row0 + i0, (const T*)c->xa + j0, (T)1, (T)0);
+                if (sym && j0 > i0) {
+                    // R_J += u_J o (H^T v_I)
+                    BLAS_CHECK(c, wgemv(c->blas, rocblas_operation_transpose, (int)nr, (int)nc, 1.0, (const T*)G, (int)nr, v + i0, 0.0, tmp));
+                    hipLaunchKernelGGL((wide_mulacc_kernel<T>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, R + j0, u + j0, (const T*)tmp, nc, 1);
+                    // C_I += v_I o (H u_J)
+                    BLAS_CHECK(c, wgemv(c->blas, rocblas_operation_none, (int)nr, (int)nc, 1.0, (const T*)G, (int)nr, u + j0, 0.0, tmp));
+                    hipLaunchKernelGGL((wide_mulacc_kernel<T>), dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream, C + i0, v + i0, (const T*)tmp, nr, 1);
+                    // T'_J += H^T (v o X)_I
+                    BLAS_CHECK(c, wgemm(c->blas, rocblas_operation_none, rocblas_operation_none, D, (int)nc, (int)nr, 1.0, (const T*)VX + i0 * D, D, (const T*)G, (int)nr,
+                                        1.0, Tp + j0 * D, D));
+                }
                 // R_I += u_I o (H v_J)
                 BLAS_CHECK(c, wgemv(c->blas, rocblas_operation_none, (int)nr, (int)nc, 1.0, (const T*)G, (int)nr, v + j0, 0.0, tmp));
                 hipLaunchKernelGGL((wide_mulacc_kernel<T>), dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream, R + i0, u + i0, (const T*)tmp, nr, 1);

@@ -196,7 +196,7 @@ def _free_port():
     return port
 
 
-def _dist_worker(rank, world, port, q, shape=(9000, 40, 128)):
+def _dist_worker(rank, world, port, q, shape=(9000, 40, 128), wide_reg=1):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
@@ -206,6 +206,7 @@ def _dist_worker(rank, world, port, q, shape=(9000, 40, 128)):
         N, D, M = shape              # (9000, 40, 128): three 4096-row tiles, 22 CG steps
         X, y, Z, hyp = _problem(N, D, M, seed=3)
         ctx = DistHipContext(X, y, M, "rbf", collectives="callbacks")
+        ctx.set_option("wide_reg", wide_reg)
         ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
         v = torch.zeros(N, dtype=torch.float64, device=ctx.device)
         r = ctx.objective_and_grad(v, True, 1.0, 100, 40)
@@ -215,11 +216,14 @@ def _dist_worker(rank, world, port, q, shape=(9000, 40, 128)):
         dist.destroy_process_group()
 
 
-def test_wide_inputs_on_two_ranks():
+@pytest.mark.parametrize("wide_reg", [1, 0])
+def test_wide_inputs_on_two_ranks(wide_reg):
+    """wide_reg = 1: the register-resident passes in their cyclic form; 0: the Gram tiles, three row tiles dealt 2 + 1 over the two ranks
+    (symmetric use of the tiles in the mat-vec and in the gradient pass, mirrored sums landing in the other rank's rows)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q, (9000, 40, 128), wide_reg)) for r in range(2)]
     for p in procs:
         p.start()
     out = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
