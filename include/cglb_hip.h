@@ -255,6 +255,7 @@ int cglb_get_stat(cglb_ctx* ctx, const char* name, double* value);
  * "final_matvec" (cglb_objective_and_grad after a solve: 1 recomputes K v with a mat-vec like models.py:280; 0, the default, takes K v = e - r
  *  from the residual r the PCG recurrence carries - exact at the start of a solve and after every restart step; measured difference at the
  *  headline shape: bound <= 3e-15 relative, gradient <= 1e-10 of its largest entry, one N^2 pass saved per evaluation) |
+ * "wide_grad_sym" (tiled K_ff gradient pass of wide inputs: 1, default - tiles on and right of the diagonal only; 0 - every tile) |
  * "wide_reg" (inputs of 33 ... 96 dimensions, fp64: 1, default - the symmetric K_ff mat-vec and the K_ff gradient pass stay register-resident,
  *  column operands handed out by v_fmac_f64 row_newbcast; 0 - both go through the Gram tiles like every other product of a wide input) |
  * "drop_weighted_operand" (any value: forget the pre-weighted copy cglb_vec_update_p_seg made of its p - for callers that modify p before the next mat-vec);
