@@ -164,6 +164,33 @@ def test_mid_width_low_precision_level_and_switching_the_path_on_one_context():
     ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+def test_wide_inputs_in_fp32(kind):
+    """fp32 contexts keep every product of a wide input on the Gram tiles (sgemm); against the fp64 oracle at single-precision tolerances."""
+    from cglb_amd.hip_context import HipContext
+    N, D, M = 3000, 50, 40
+    X, y, Z = orc.synthetic_problem(N, D, M, seed=4)
+    rng = np.random.default_rng(1)
+    hyp = orc.Hypers(rng.uniform(0.8, 1.6, size=D) * np.sqrt(D), 1.3, 0.3, 0.15, Z, 1e-4)
+    ctx = HipContext(X, y, M, kind, dtype=torch.float32)
+    ctx.set_hypers(hyp.lengthscales, hyp.variance, hyp.noise, hyp.mean, Z, hyp.jitter)
+    ctx.setup()
+    cov = orc.dense_cov(kind, X, hyp)
+    p = rng.standard_normal(N)
+    Ap = ctx.matvec(torch.from_numpy(p).float()).double().cpu().numpy()
+    np.testing.assert_allclose(Ap, cov @ p, rtol=0, atol=2e-5 * np.abs(cov @ p).max())
+    v = torch.zeros(N, dtype=torch.float32, device=ctx.device)
+    res = ctx.objective_and_grad(v, True, 1.0, 100, 40)
+    ref = orc.objective(kind, X, y, hyp, np.zeros(N), True, 1.0, 100, 40, cov=cov)
+    assert abs(res.steps - ref.steps) <= 1
+    refg = orc.objective(kind, X, y, hyp, v.double().cpu().numpy(), run_cg=False, with_grad=True, cov=cov)
+    assert res.bound == pytest.approx(refg.bound, rel=2e-6)
+    for key in ("lengthscales", "Z", "variance", "noise"):
+        b = np.asarray(refg.grad[key])
+        np.testing.assert_allclose(np.asarray(res.grad[key]), b, rtol=0, atol=5e-4 * max(np.abs(b).max(), 1e-3 * abs(refg.bound)), err_msg=key)
+    ctx.close()
+
+
 def test_wide_inducing_point_selection_and_backend_training_step():
     """Greedy conditional-variance selection and three L-BFGS-B iterations through the backend mirror at D = 50."""
     from cglb_amd.backend import BACKENDS, CGLBConfig, INDUCING_VARIABLE_CONFIGS, KERNEL_CONFIGS
