@@ -16,7 +16,7 @@ from cglb_amd.hip_context import HipContext, _ptr
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-N, D, M = int(os.environ.get("N", 100000)), 8, int(os.environ.get("M", 1024))
+N, D, M = int(os.environ.get("N", 100000)), int(os.environ.get("D", 8)), int(os.environ.get("M", 1024))
 X, y, Z = synthetic_problem(N, D, M, 0)
 h = trained_like_hypers(D)
 per, parts = row_partition(N, world)
