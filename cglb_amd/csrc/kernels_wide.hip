@@ -171,6 +171,56 @@ __global__ __launch_bounds__(256) void wide_rowcol_kernel(const T* __restrict__ 
     if (live) part[(int64_t)blockIdx.y * nr + i] = acc;
 }
 
+// Gradient pass, one tile: G <- H = derivative factor of the Gram entries (in place, for the moment GEMMs that follow) and, in the same
+// pass over the tile, the row sums against v_J (and u_J) and the column sums against u_I (and v_I) that four GEMVs over the stored tile
+// used to take.  Block = 256 rows x CSLICE columns; row partials part_*[slice][i], column partials pc_*[(bx * 4 + wave)][j].
+// BOTH: the tile also stands for its mirror image (symmetric use), which needs the second sum of each kind.
+template <typename T, int KIND, bool BOTH>
+__global__ __launch_bounds__(256) void wide_grad_profile_kernel(T* __restrict__ G, int64_t ld, int64_t nr, int64_t nc, const T* __restrict__ arow,
+                                                                const T* __restrict__ acol, const T* __restrict__ urow, const T* __restrict__ vrow,
+                                                                const T* __restrict__ ucol, const T* __restrict__ vcol, T* __restrict__ part_v,
+                                                                T* __restrict__ part_u, T* __restrict__ pc_u, T* __restrict__ pc_v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j0 = (int64_t)blockIdx.y * CSLICE;
+    const int64_t j1 = j0 + CSLICE < nc ? j0 + CSLICE : nc;
+    const bool live = i < nr;
+    const int64_t ii = live ? i : nr - 1;
+    const T ai = arow[ii];
+    const T ui = live ? urow[ii] : T(0);
+    const T vi = (BOTH && live) ? vrow[ii] : T(0);
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    T av = 0, au = 0;
+    for (int64_t j = j0; j < j1; ++j) {
+        T h = T(0);
+        if (live) {
+            h = wide_profile<T, KIND, 1>(G[ii + j * ld], ai, acol[j]);
+            G[ii + j * ld] = h;
+        }
+        av = tfma<T>(h, vcol[j], av);
+        const T cu = wave_sum(h * ui);
+        if (lane == 0) pc_u[chunk * nc + j] = cu;
+        if constexpr (BOTH) {
+            au = tfma<T>(h, ucol[j], au);
+            const T cv = wave_sum(h * vi);
+            if (lane == 0) pc_v[chunk * nc + j] = cv;
+        }
+    }
+    if (live) {
+        part_v[(int64_t)blockIdx.y * nr + i] = av;
+        if constexpr (BOTH) part_u[(int64_t)blockIdx.y * nr + i] = au;
+    }
+}
+// out[i] += a[i] * sum_q part[q][i]   (fixed order)
+template <typename T>
+__global__ __launch_bounds__(256) void wide_partsum_mulacc_kernel(const T* __restrict__ part, int nq, int64_t n, const T* __restrict__ a, T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T s = 0;
+    for (int q = 0; q < nq; ++q) s += part[(int64_t)q * n + i];
+    out[i] = tfma<T>(a[i], s, out[i]);
+}
+
 template <typename T> __global__ __launch_bounds__(256) void wide_fill_kernel(T* __restrict__ x, int64_t n, T v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = v;
@@ -442,7 +492,7 @@ int wide_grad_kff(cglb_ctx* c, const void* v_full_, const void* u_rows_, int64_t
         T* Tp = (T*)c->wS1;
         T* VX = Tp + (size_t)N * D;
         T *R = (T*)c->wR, *C = (T*)c->wC;   // R: rows of this call, C: all columns
-        CGLB_TRY(wensure(c, &c->wpart, &c->wpart_cap, (size_t)(TILE / CSLICE) * TILE * sizeof(T)));
+        CGLB_TRY(wensure(c, &c->wpart, &c->wpart_cap, (size_t)4 * (TILE / CSLICE) * TILE * sizeof(T)));   // two row-partial and two column-partial slabs
         T* tmp = (T*)c->wpart;
         HIP_CHECK(c, hipMemsetAsync(Tp, 0, (size_t)nrows * D * sizeof(T), c->stream));
         HIP_CHECK(c, hipMemsetAsync(R, 0, (size_t)nrows * sizeof(T), c->stream));
@@ -459,25 +509,32 @@ int wide_grad_kff(cglb_ctx* c, const void* v_full_, const void* u_rows_, int64_t
             for (int64_t j0 = sym ? i0 : 0; j0 < N; j0 += TILE) {
                 const int64_t nc = std::min(TILE, N - j0);
                 CGLB_TRY(gram_tile<T>(c, (const T*)c->Xs + (row0 + i0) * D, nr, (const T*)c->Xs + j0 * D, nc, G, nr));
-                hipLaunchKernelGGL((wide_profile_kernel<T, KIND, 1>), dim3((unsigned)((nr + 255) / 256), (unsigned)nc), dim3(256), 0, c->stream, G, nr, nr, nc,
-                                   (const T*)c->xa + row0 + i0, (const T*)c->xa + j0, (T)1, (T)0);
-                if (sym && j0 > i0) {
-                    // R_J += u_J o (H^T v_I)
-                    BLAS_CHECK(c, wgemv(c->blas, rocblas_operation_transpose, (int)nr, (int)nc, 1.0, (const T*)G, (int)nr, v + i0, 0.0, tmp));
-                    hipLaunchKernelGGL((wide_mulacc_kernel<T>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, R + j0, u + j0, (const T*)tmp, nc, 1);
-                    // C_I += v_I o (H u_J)
-                    BLAS_CHECK(c, wgemv(c->blas, rocblas_operation_none, (int)nr, (int)nc, 1.0, (const T*)G, (int)nr, u + j0, 0.0, tmp));
-                    hipLaunchKernelGGL((wide_mulacc_kernel<T>), dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream, C + i0, v + i0, (const T*)tmp, nr, 1);
-                    // T'_J += H^T (v o X)_I
-                    BLAS_CHECK(c, wgemm(c->blas, rocblas_operation_none, rocblas_operation_none, D, (int)nc, (int)nr, 1.0, (const T*)VX + i0 * D, D, (const T*)G, (int)nr,
-                                        1.0, Tp + j0 * D, D));
+                const bool both = sym && j0 > i0;
+                {   // derivative factors in place + the row / column sums of the tile in the same pass
+                    const unsigned gx = (unsigned)((nr + 255) / 256);
+                    const int nslice = (int)((nc + CSLICE - 1) / CSLICE), nchunk = (int)gx * 4;
+                    T* part_v = tmp;                                   // [nslice][nr]
+                    T* part_u = part_v + (int64_t)nslice * nr;         // [nslice][nr]
+                    T* pc_u = part_u + (int64_t)nslice * nr;           // [nchunk][nc]
+                    T* pc_v = pc_u + (int64_t)nchunk * nc;             // [nchunk][nc]
+                    const T* ar = (const T*)c->xa + row0 + i0;
+                    const T* ac = (const T*)c->xa + j0;
+                    if (both)
+                        hipLaunchKernelGGL((wide_grad_profile_kernel<T, KIND, true>), dim3(gx, (unsigned)nslice), dim3(256), 0, c->stream, G, nr, nr, nc, ar, ac, u + i0,
+                                           v + i0, u + j0, v + j0, part_v, part_u, pc_u, pc_v);
+                    else
+                        hipLaunchKernelGGL((wide_grad_profile_kernel<T, KIND, false>), dim3(gx, (unsigned)nslice), dim3(256), 0, c->stream, G, nr, nr, nc, ar, ac, u + i0,
+                                           (const T*)nullptr, (const T*)nullptr, v + j0, part_v, part_u, pc_u, pc_v);
+                    // R_I += u_I o (H v_J) ; C_J += v_J o (H^T u_I)
+                    hipLaunchKernelGGL((wide_partsum_mulacc_kernel<T>), dim3(gx), dim3(256), 0, c->stream, (const T*)part_v, nslice, nr, u + i0, R + i0);
+                    hipLaunchKernelGGL((wide_partsum_mulacc_kernel<T>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, (const T*)pc_u, nchunk, nc, v + j0, C + j0);
+                    if (both) {   // the mirror image: C_I += v_I o (H u_J) ; R_J += u_J o (H^T v_I) ; T'_J += H^T (v o X)_I
+                        hipLaunchKernelGGL((wide_partsum_mulacc_kernel<T>), dim3(gx), dim3(256), 0, c->stream, (const T*)part_u, nslice, nr, v + i0, C + i0);
+                        hipLaunchKernelGGL((wide_partsum_mulacc_kernel<T>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, (const T*)pc_v, nchunk, nc, u + j0, R + j0);
+                        BLAS_CHECK(c, wgemm(c->blas, rocblas_operation_none, rocblas_operation_none, D, (int)nc, (int)nr, 1.0, (const T*)VX + i0 * D, D, (const T*)G, (int)nr,
+                                            1.0, Tp + j0 * D, D));
+                    }
                 }
-                // R_I += u_I o (H v_J)
-                BLAS_CHECK(c, wgemv(c->blas, rocblas_operation_none, (int)nr, (int)nc, 1.0, (const T*)G, (int)nr, v + j0, 0.0, tmp));
-                hipLaunchKernelGGL((wide_mulacc_kernel<T>), dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream, R + i0, u + i0, (const T*)tmp, nr, 1);
-                // C_J += v_J o (H^T u_I)
-                BLAS_CHECK(c, wgemv(c->blas, rocblas_operation_transpose, (int)nr, (int)nc, 1.0, (const T*)G, (int)nr, u + i0, 0.0, tmp));
-                hipLaunchKernelGGL((wide_mulacc_kernel<T>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, C + j0, v + j0, (const T*)tmp, nc, 1);
                 // T'_I += H (v o X)_J      (row-major [i][D] == column-major D x nr)
                 BLAS_CHECK(c, wgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, D, (int)nr, (int)nc, 1.0, (const T*)VX + j0 * D, D, (const T*)G, (int)nr,
                                     1.0, Tp + i0 * D, D));
